@@ -1,0 +1,84 @@
+// device_scene.h -- how a scene is laid out in HBM for the gfx950 kernels, and
+// the struct the kernels receive by value.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/mirt.h"
+
+namespace mirt {
+
+// A reference to a BVH child or a stack entry.
+//   bit 31      : 1 = leaf (a shape), 0 = inner node
+//   leaf        : bits 28..30 = MIRT_SHAPE_* kind, bits 0..27 = index into the sorted shape array
+//   inner node  : bits 0..30 = index into the DNode array
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_KIND_SHIFT = 28;
+constexpr uint32_t REF_INDEX_MASK = 0x0FFFFFFFu;
+constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^28 - 1
+
+// One inner node of the traversal tree: one 128-byte line (the L2 line size on
+// gfx950) holding the boxes of BOTH children, so that one fetch serves two slab
+// tests and the near child can be taken first.
+//
+// box[c][axis][0/1] = min/max of child c along axis.  For an inner child this
+// is the `bounds` of that BVHMember::Node (src/bvh.rs:95-99), whose slab test
+// decides hit/miss exactly as the reference does.  For a leaf child -- which
+// carries no box in the reference and is never slab-tested there -- it is the
+// shape's own bounding box, used only to order and distance-prune, never to
+// reject.
+struct alignas(128) DNode {
+    double box[2][3][2];
+    uint32_t child[2];
+    uint32_t pad[6];
+};
+static_assert(sizeof(DNode) == 128, "DNode must be one 128-byte line");
+
+// One shape: 96 bytes, the first 32 of which are all a sphere test needs.
+struct alignas(32) DShape {
+    double f[10];       // same meaning as mirt_shape.f
+    uint32_t kind;      // MIRT_SHAPE_*
+    uint32_t material;  // index into materials
+    uint32_t cls;       // shade class of its material (SHADE_*), precomputed
+    uint32_t pad;
+};
+static_assert(sizeof(DShape) == 96, "DShape is 96 bytes");
+
+// Shade classes: paths are binned by this after each closest-hit query so that a
+// wave of the shade kernel runs one material/texture kind.
+enum ShadeClass : uint32_t {
+    SHADE_MISS = 0,
+    SHADE_LAMBERTIAN_CONSTANT = 1,
+    SHADE_LAMBERTIAN_CHECKER = 2,
+    SHADE_LAMBERTIAN_NOISE = 3,
+    SHADE_LAMBERTIAN_IMAGE = 4,
+    SHADE_METAL = 5,
+    SHADE_DIELECTRIC = 6,
+    SHADE_LIGHT = 7,
+    SHADE_NUM_CLASSES = 8
+};
+
+// Most levels the traversal kernels can walk.  The fast kernel keeps a per-lane
+// stack of this many entries in LDS; the reference-order kernel keeps as many
+// frames in private memory.
+constexpr int MAX_TREE_HEIGHT = 24;
+
+// What the kernels see (passed by value as a kernel argument).
+struct DScene {
+    const DNode* nodes;              // inner nodes; root = nodes[root_ref] unless the root is a leaf
+    const DShape* shapes;            // BVH-sorted order
+    const mirt_bvh_member* members;  // the reference's own member array (post-order, root last)
+    const mirt_material* materials;
+    const mirt_texture* textures;
+    const mirt_perlin* perlins;
+    const mirt_image* images;  // .rgb holds DEVICE pointers
+    uint32_t n_shapes;
+    uint32_t n_members;  // 0 when the scene came without a BVH
+    uint32_t n_nodes;
+    uint32_t root_ref;  // REF_LEAF|... when the scene has a single shape
+    // bounds of the root BVHMember::Node, [axis][min,max]: every other box lives in
+    // its parent's DNode, the root has no parent.  Tested first, like bvh.rs:61 does.
+    double root_box[3][2];
+};
+
+}  // namespace mirt

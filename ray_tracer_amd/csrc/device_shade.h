@@ -1,0 +1,290 @@
+// device_shade.h -- camera rays, hit geometry, textures, Perlin noise and material
+// scattering as __device__ f64 code for gfx950, in the reference's operation order:
+//   Camera::ray, random_in_unit_disk     src/camera.rs:65-88
+//   Hit::new, sphere_uv                  src/hittable.rs:27-52, 732-749
+//   Lambertian/Metal/Dielectric scatter  src/material.rs:51-131
+//   DiffuseLight                         src/material.rs:144-152
+//   random_in_unit_sphere, reflect,
+//   refract, schlick                     src/material.rs:211-243
+//   Texture::value (4 kinds)             src/texture.rs:24-28, 45-54, 82-87, 106-122
+//   Perlin::noise / turbulence           src/perlin.rs:38-86, 100-122
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/mirt_rng.h"
+#include "device_intersect.h"
+
+namespace mirt {
+
+// Draws of one stage of one camera path (include/mirt_rng.h).
+struct PathRng {
+    uint64_t stream;
+    uint32_t stage;
+    uint32_t k;
+    __device__ __forceinline__ double random_double() { return mirt_rng_double(stream, stage, k++); }  // util.rs:8-10
+};
+
+// camera.rs:78-88
+__device__ __forceinline__ void random_in_unit_disk(PathRng& rng, double* x, double* y) {
+    double px, py;
+    do {
+        double a = rng.random_double();
+        double b = rng.random_double();
+        px = a * 2.0 - 1.0;
+        py = b * 2.0 - 1.0;
+    } while (px * px + py * py + 0.0 * 0.0 >= 1.0);
+    *x = px;
+    *y = py;
+}
+
+// renderer.rs:74-80 + camera.rs:65-76 for pixel idx, with the sampler at stage 0.
+__device__ __forceinline__ RayD camera_ray(const mirt_camera& c, uint32_t width, uint32_t height, uint32_t idx,
+                                           PathRng& rng) {
+    const uint32_t i = idx % width;
+    const uint32_t j = height - 1 - idx / width;
+    const double s = ((double)i + rng.random_double()) / (double)width;
+    const double t = ((double)j + rng.random_double()) / (double)height;
+    double rx, ry;
+    random_in_unit_disk(rng, &rx, &ry);
+    // rd = lens_radius * p  (f64 * Vec3 -> component * lens_radius)
+    rx = rx * c.lens_radius;
+    ry = ry * c.lens_radius;
+    const V3 cu = v3(c.u[0], c.u[1], c.u[2]), cv = v3(c.v[0], c.v[1], c.v[2]);
+    const V3 origin = v3(c.origin[0], c.origin[1], c.origin[2]);
+    const V3 llc = v3(c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2]);
+    const V3 horizontal = v3(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
+    const V3 vertical = v3(c.vertical[0], c.vertical[1], c.vertical[2]);
+    const V3 offset = cu * rx + cv * ry;
+    const V3 direction = llc + s * horizontal + t * vertical - origin - offset;
+    const double time = c.time_start + rng.random_double() * (c.time_end - c.time_start);
+    return RayD{origin + offset, direction, time};
+}
+
+// ------------------------------------------------------------------ hit geometry
+struct Surface {
+    V3 p;       // ray.point_at(t)
+    V3 normal;  // flipped against the ray, hittable.rs:36-41
+    bool front_facing;
+    uint32_t material;
+    // what sphere_uv / the rect u,v need, computed on demand by surface_uv()
+    V3 outward_normal;
+    uint32_t kind;
+    double ua, ub, a0, a1, b0, b1;  // rects: in-plane hit coordinates and extents
+};
+
+// Rebuilds what Hit::new stored for the closest hit {t, prim, side} of ray r.
+__device__ __forceinline__ Surface surface_at(const DScene& sc, const RayD& r, double t, uint32_t prim, int side) {
+    const DShape* __restrict__ s = sc.shapes + prim;
+    const double* __restrict__ f = s->f;
+    Surface h;
+    h.material = s->material;
+    h.kind = s->kind;
+    h.p = r.o + t * r.d;  // ray.rs:31-33
+    h.ua = h.ub = h.a0 = h.a1 = h.b0 = h.b1 = 0.0;
+    uint32_t kind = s->kind;
+    double a0 = f[0], a1 = f[1], b0 = f[2], b1 = f[3];
+    if (kind == MIRT_SHAPE_CUBE) {
+        // side -> the rect Cube::new built for it (hittable.rs:405-412)
+        const double p0x = f[0], p0y = f[1], p0z = f[2], p1x = f[3], p1y = f[4], p1z = f[5];
+        if (side < 2) {
+            kind = MIRT_SHAPE_XY_RECT; a0 = p0x; a1 = p1x; b0 = p0y; b1 = p1y;
+        } else if (side < 4) {
+            kind = MIRT_SHAPE_XZ_RECT; a0 = p0x; a1 = p1x; b0 = p0z; b1 = p1z;
+        } else {
+            kind = MIRT_SHAPE_YZ_RECT; a0 = p0y; a1 = p1y; b0 = p0z; b1 = p1z;
+        }
+    }
+    switch (kind) {
+        case MIRT_SHAPE_SPHERE:
+            h.outward_normal = (h.p - v3(f[0], f[1], f[2])) / f[3];  // hittable.rs:130
+            break;
+        case MIRT_SHAPE_MOVING_SPHERE:
+            h.outward_normal = (h.p - moving_center(f, r.time)) / f[3];  // hittable.rs:514
+            break;
+        case MIRT_SHAPE_XY_RECT:
+            h.outward_normal = v3(0.0, 0.0, 1.0);
+            h.ua = r.o.x + t * r.d.x; h.ub = r.o.y + t * r.d.y;
+            break;
+        case MIRT_SHAPE_XZ_RECT:
+            h.outward_normal = v3(0.0, 1.0, 0.0);
+            h.ua = r.o.x + t * r.d.x; h.ub = r.o.z + t * r.d.z;
+            break;
+        default:  // MIRT_SHAPE_YZ_RECT
+            h.outward_normal = v3(1.0, 0.0, 0.0);
+            h.ua = r.o.y + t * r.d.y; h.ub = r.o.z + t * r.d.z;
+            break;
+    }
+    h.kind = kind;
+    h.a0 = a0; h.a1 = a1; h.b0 = b0; h.b1 = b1;
+    h.front_facing = dot(r.d, h.outward_normal) < 0.0;
+    h.normal = h.front_facing ? h.outward_normal : -h.outward_normal;
+    return h;
+}
+
+// Hit::u(), Hit::v(): only image textures read them, so they are computed only there.
+__device__ __forceinline__ void surface_uv(const Surface& h, double* u, double* v) {
+    if (h.kind == MIRT_SHAPE_SPHERE || h.kind == MIRT_SHAPE_MOVING_SPHERE) {
+        // sphere_uv, hittable.rs:732-749
+        const double PI = 3.14159265358979323846264338327950288;
+        const double TAU = 6.28318530717958647692528676655900577;
+        const double theta = acos(-h.outward_normal.y);
+        const double phi = atan2(-h.outward_normal.z, h.outward_normal.x) + PI;
+        *u = phi / TAU;
+        *v = theta / PI;
+    } else {
+        *u = (h.ua - h.a0) / (h.a1 - h.a0);  // hittable.rs:199-200, 263-264, 327-328
+        *v = (h.ub - h.b0) / (h.b1 - h.b0);
+    }
+}
+
+// ------------------------------------------------------------------------ perlin
+// `x as i32` of Rust for an f64 that is already integral: saturating, NaN -> 0.
+__device__ __forceinline__ int32_t f64_as_i32(double x) {
+    if (x != x) return 0;
+    if (x <= -2147483648.0) return (int32_t)0x80000000;
+    if (x >= 2147483647.0) return 0x7FFFFFFF;
+    return (int32_t)x;
+}
+__device__ __forceinline__ uint32_t f64_as_u32(double x) {
+    if (x != x) return 0u;
+    if (x <= 0.0) return 0u;
+    if (x >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+// perlin.rs:52-85 + 100-122.  Tables may live in LDS or in global memory.
+__device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, const int32_t* __restrict__ perm_x,
+                                               const int32_t* __restrict__ perm_y, const int32_t* __restrict__ perm_z,
+                                               V3 p) {
+    const double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    const double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int32_t i = f64_as_i32(fx), j = f64_as_i32(fy), k = f64_as_i32(fz);
+    const double uu = u * u * (3.0 - 2.0 * u);
+    const double vv = v * v * (3.0 - 2.0 * v);
+    const double ww = w * w * (3.0 - 2.0 * w);
+    double accumulator = 0.0;
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+        const int32_t px = perm_x[(int32_t)((uint32_t)i + (uint32_t)di) & 255];
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            const int32_t py = perm_y[(int32_t)((uint32_t)j + (uint32_t)dj) & 255];
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                const int32_t pz = perm_z[(int32_t)((uint32_t)k + (uint32_t)dk) & 255];
+                const int32_t index = px ^ py ^ pz;
+                const double* __restrict__ g = vecs + 3 * index;
+                // weight.dot(sample): (u-i)*gx + (v-j)*gy + (w-k)*gz
+                const double color = (u - (double)di) * g[0] + (v - (double)dj) * g[1] + (w - (double)dk) * g[2];
+                // perlin.rs:112-114: i*uu + (1-i)*(1-uu) is exactly uu for i = 1 and exactly
+                // 1-uu for i = 0 (uu is finite and >= 0 for any finite p)
+                const double wi = di ? uu : (1.0 - uu);
+                const double wj = dj ? vv : (1.0 - vv);
+                const double wk = dk ? ww : (1.0 - ww);
+                accumulator += color * wi * wj * wk;
+            }
+        }
+    }
+    return accumulator;
+}
+
+// perlin.rs:38-50
+__device__ __forceinline__ double perlin_turbulence(const double* __restrict__ vecs, const int32_t* __restrict__ perm_x,
+                                                    const int32_t* __restrict__ perm_y,
+                                                    const int32_t* __restrict__ perm_z, V3 p, int depth) {
+    V3 current_p = p;
+    double weight = 1.0;
+    double accumulator = 0.0;
+    for (int i = 0; i < depth; ++i) {
+        accumulator += weight * perlin_noise(vecs, perm_x, perm_y, perm_z, current_p);
+        weight *= 0.5;
+        current_p = current_p * 2.0;
+    }
+    return fabs(accumulator);
+}
+
+// ---------------------------------------------------------------------- textures
+// texture.rs:195-205
+__device__ __forceinline__ double fclamp(double x, double lo, double hi) {
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+
+// Texture::value (texture.rs:184-193).  Checker nesting is followed iteratively.
+// `lds_tables` = the scene's first `n_staged` Perlin tables as the shade kernel staged them
+// in LDS (null / 0 when it staged none); other tables are read from global memory.
+__device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, const Surface& h,
+                                            const mirt_perlin* lds_tables, uint32_t n_staged) {
+    for (int guard = 0; guard < 64; ++guard) {
+        const mirt_texture* __restrict__ t = sc.textures + tex;
+        const uint32_t kind = t->kind;
+        if (kind == MIRT_TEX_CONSTANT) return v3(t->color[0], t->color[1], t->color[2]);
+        if (kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
+            const double sines = sin(10.0 * h.p.x) * sin(10.0 * h.p.y) * sin(10.0 * h.p.z);
+            tex = (sines < 0.0) ? t->odd : t->even;
+            continue;
+        }
+        if (kind == MIRT_TEX_NOISE) {  // texture.rs:82-87
+            double turb;
+            if (t->perlin < n_staged) {
+                const mirt_perlin* pl = lds_tables + t->perlin;
+                turb = perlin_turbulence(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
+            } else {
+                const mirt_perlin* __restrict__ pl = sc.perlins + t->perlin;
+                turb = perlin_turbulence(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
+            }
+            const double turbulence = t->scale * h.p.z + 10.0 * turb;
+            const double c = (1.0 * 0.5) * (1.0 + sin(turbulence));
+            return v3(c, c, c);
+        }
+        // MIRT_TEX_IMAGE, texture.rs:106-122
+        double u, v;
+        surface_uv(h, &u, &v);
+        const mirt_image* __restrict__ im = sc.images + t->image;
+        u = fclamp(u, 0.0, 1.0);
+        v = 1.0 - fclamp(v, 0.0, 1.0);
+        uint32_t i = f64_as_u32(u * (double)im->width);
+        uint32_t j = f64_as_u32(v * (double)im->height);
+        if (i > im->width - 1) i = im->width - 1;
+        if (j > im->height - 1) j = im->height - 1;
+        const double color_scale = 1.0 / 255.0;
+        const uint8_t* __restrict__ px = im->rgb + 3 * ((size_t)j * im->width + i);
+        return v3((double)px[0] * color_scale, (double)px[1] * color_scale, (double)px[2] * color_scale);
+    }
+    return v3(0.0, 0.0, 0.0);
+}
+
+// --------------------------------------------------------------------- materials
+// material.rs:211-225
+__device__ __forceinline__ V3 random_in_unit_sphere(PathRng& rng) {
+    V3 p;
+    do {
+        double a = rng.random_double();
+        double b = rng.random_double();
+        double c = rng.random_double();
+        p = v3(a * 2.0 - 1.0, b * 2.0 - 1.0, c * 2.0 - 1.0);
+    } while (square_length(p) >= 1.0);
+    return p;
+}
+// material.rs:227-229
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0 * dot(v, n)) * n; }
+// material.rs:231-237
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, double etai_over_etat) {
+    const double cos_theta = fmin(dot(-uv, n), 1.0);
+    const V3 perpendicular = etai_over_etat * (uv + cos_theta * n);
+    const V3 parallel = (-sqrt(fabs(1.0 - square_length(perpendicular)))) * n;
+    return perpendicular + parallel;
+}
+// material.rs:239-243; powi(5) = x * (x*x)*(x*x)
+__device__ __forceinline__ double schlick(double cosine, double ref_idx) {
+    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    r0 *= r0;
+    const double x = 1.0 - cosine;
+    const double x2 = x * x;
+    const double x4 = x2 * x2;
+    return r0 + (1.0 - r0) * (x * x4);
+}
+
+}  // namespace mirt

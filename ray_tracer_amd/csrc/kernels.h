@@ -1,0 +1,429 @@
+// kernels.h -- the gfx950 kernels of the wavefront path tracer.
+//
+// renderer.rs's per-pixel loop (src/renderer.rs:64-115) is restructured into
+// passes.  One pass holds `n_paths` camera paths = B samples of every pixel of
+// the range, one path per slot of a structure-of-arrays state in HBM, and runs
+//
+//   raygen                                   renderer.rs:74-82 + camera.rs:65-76
+//   for bounce in 0 .. max_depth:
+//       extend   closest hit of every live path     renderer.rs:103 -> bvh.rs:37-80
+//       bin      sort the live queue by shade class (material/texture kind)
+//       shade    emit / scatter / terminate, append survivors to the next live
+//                queue                              renderer.rs:104-114 -> material.rs
+//   accumulate   pixel += sample radiance, in sample order   renderer.rs:83
+//
+// and after the last pass `resolve` does renderer.rs:85-89 and the u8 cast.
+//
+// Queues hold slot indices; counts live in device memory (`counters`), so the
+// host enqueues a whole pass without reading anything back.  Kernels are
+// launched with a fixed grid and stride over the work; a kernel whose queue is
+// empty returns at once.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_shade.h"
+
+namespace mirt {
+
+constexpr int BLOCK = 256;               // threads per workgroup (4 waves)
+constexpr int WAVES_PER_BLOCK = BLOCK / 64;
+constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;
+constexpr uint32_t HIT_SIDE_SHIFT = 28;
+
+// Per-pass path state, structure of arrays, `capacity` slots each.
+struct Paths {
+    double *ox, *oy, *oz, *dx, *dy, *dz, *time;  // current ray of the path
+    double *bx, *by, *bz;                        // product of attenuations so far
+    double *hit_t;                               // closest hit of the current ray
+    uint32_t* hit_ref;                           // shape index | side << 28, or HIT_MISS
+    double *rr, *rg, *rb;                        // radiance of the finished path
+    uint64_t* stream;                            // sampler key of the path
+    uint32_t* live[2];                           // live queues (slot indices), ping-pong by bounce parity
+    uint8_t* cls_q;                              // shade class of live entry i (queue order)
+    uint32_t* cls_queue;                         // SHADE_NUM_CLASSES queues of `capacity` slots
+    uint32_t* counters;                          // see Counters
+    unsigned long long* segments;                // running total of closest-hit queries
+    uint32_t capacity;
+};
+
+// Layout of Paths::counters for a pass of depth D (all zeroed at pass start):
+//   [0 .. D]                 live[b]     number of live paths entering bounce b (live[0] unused: = n_paths)
+//   [D+1 .. D+1+8D)          cls[b][c]   paths of shade class c at bounce b
+struct Counters {
+    uint32_t depth;
+    __host__ __device__ uint32_t live(uint32_t b) const { return b; }
+    __host__ __device__ uint32_t cls(uint32_t b, uint32_t c) const { return depth + 1 + b * SHADE_NUM_CLASSES + c; }
+    __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES; }
+};
+
+struct RenderParams {
+    mirt_camera cam;
+    double background[3];
+    uint32_t width, height;
+    uint32_t max_depth;
+    uint32_t pixel_begin;   // first pixel idx of the range
+    uint32_t n_pixels;      // pixels in the range
+    uint32_t sample_base;   // first sample index of this pass
+    uint32_t n_samples;     // samples per pixel in this pass (B)
+    uint32_t n_paths;       // n_pixels * n_samples
+    uint64_t seed;
+    double t_min, t_max;    // 0.001, +inf (renderer.rs:103)
+    int use_bvh;
+    int traversal;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint32_t mbcnt_lt(unsigned long long mask) {
+    // number of set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---------------------------------------------------------------- closest hit
+enum : int { MODE_LIST = 0, MODE_REFERENCE = 1, MODE_FAST = 2 };
+
+template <int MODE>
+__device__ __forceinline__ HitRec closest_hit(const DScene& sc, const RayD& r, double t_min, double t_max,
+                                              uint32_t* stack, int tid) {
+    if (MODE == MODE_LIST) return list_closest(sc, r, t_min, t_max);
+    if (MODE == MODE_REFERENCE) return bvh_closest_reference(sc, r, t_min, t_max);
+    return bvh_closest_fast<BLOCK>(sc, r, t_min, t_max, stack, tid);
+}
+
+// Hittable::hit for caller-supplied rays (array of structs, as the C ABI hands them over).
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_intersect(DScene sc, const mirt_ray* __restrict__ rays, size_t n,
+                                                     double t_min, double t_max, mirt_hit* __restrict__ hits) {
+    __shared__ uint32_t stack[MODE == MODE_FAST ? MAX_TREE_HEIGHT * BLOCK : 1];
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        RayD r;
+        r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
+        r.time = rays[i].time;
+        HitRec h = closest_hit<MODE>(sc, r, t_min, t_max, stack, threadIdx.x);
+        mirt_hit out;
+        out.prim = h.prim;
+        out.side = h.prim >= 0 ? h.side : 0;
+        out.t = h.prim >= 0 ? h.t : 0.0;
+        hits[i] = out;
+    }
+}
+
+// ---------------------------------------------------------------------- raygen
+// Slot s holds sample (sample_base + s / n_pixels) of pixel (pixel_begin + s % n_pixels):
+// consecutive lanes start neighbouring pixels of one sample index.
+__global__ __launch_bounds__(BLOCK) void k_raygen(Paths P, RenderParams rp) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < rp.n_paths; slot += stride) {
+        const uint32_t idx = rp.pixel_begin + slot % rp.n_pixels;
+        const uint32_t sample = rp.sample_base + slot / rp.n_pixels;
+        PathRng rng{mirt_rng_stream(rp.seed, idx, sample), 0u, 0u};
+        RayD r = camera_ray(rp.cam, rp.width, rp.height, idx, rng);
+        P.ox[slot] = r.o.x; P.oy[slot] = r.o.y; P.oz[slot] = r.o.z;
+        P.dx[slot] = r.d.x; P.dy[slot] = r.d.y; P.dz[slot] = r.d.z;
+        P.time[slot] = r.time;
+        P.bx[slot] = 1.0; P.by[slot] = 1.0; P.bz[slot] = 1.0;
+        P.stream[slot] = rng.stream;
+    }
+}
+
+// Camera rays only (array of structs), for the intersection parity check.
+__global__ __launch_bounds__(BLOCK) void k_camera_rays(mirt_camera cam, uint32_t width, uint32_t height,
+                                                       uint32_t pixel_begin, uint32_t n, uint32_t sample,
+                                                       uint64_t seed, mirt_ray* __restrict__ rays) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+        const uint32_t idx = pixel_begin + k;
+        PathRng rng{mirt_rng_stream(seed, idx, sample), 0u, 0u};
+        RayD r = camera_ray(cam, width, height, idx, rng);
+        mirt_ray out;
+        out.origin[0] = r.o.x; out.origin[1] = r.o.y; out.origin[2] = r.o.z;
+        out.direction[0] = r.d.x; out.direction[1] = r.d.y; out.direction[2] = r.d.z;
+        out.time = r.time;
+        rays[k] = out;
+    }
+}
+
+// ---------------------------------------------------------------------- extend
+// Closest hit of every live path of this bounce.  Entry i of the live queue is
+// handled by thread i mod (grid size): no atomics, no barriers.
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, Paths P, RenderParams rp, uint32_t bounce) {
+    __shared__ uint32_t stack[MODE == MODE_FAST ? MAX_TREE_HEIGHT * BLOCK : 1];
+    const Counters C{rp.max_depth};
+    const uint32_t n = bounce == 0 ? rp.n_paths : P.counters[C.live(bounce)];
+    const uint32_t* __restrict__ qin = P.live[bounce & 1];
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t slot = bounce == 0 ? i : qin[i];
+        RayD r;
+        r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
+        r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
+        r.time = P.time[slot];
+        HitRec h = closest_hit<MODE>(sc, r, rp.t_min, rp.t_max, stack, threadIdx.x);
+        uint32_t cls = SHADE_MISS;
+        uint32_t ref = HIT_MISS;
+        if (h.prim >= 0) {
+            cls = sc.shapes[h.prim].cls;
+            ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
+            P.hit_t[slot] = h.t;
+        }
+        P.hit_ref[slot] = ref;
+        P.cls_q[i] = (uint8_t)cls;
+    }
+}
+
+// ------------------------------------------------------------------------- bin
+// Sorts the live queue of this bounce by shade class: a block takes a tile of
+// BIN_TILE consecutive entries, counts its classes with wave ballots, reserves
+// one contiguous range per class with one atomic per class per block, and
+// writes the slot indices there in queue order.
+constexpr int BIN_ITEMS = 8;
+constexpr int BIN_TILE = BLOCK * BIN_ITEMS;
+
+__global__ __launch_bounds__(BLOCK) void k_bin(Paths P, RenderParams rp, uint32_t bounce) {
+    __shared__ uint32_t s_wave[WAVES_PER_BLOCK][SHADE_NUM_CLASSES];  // per wave: count, then offset inside the block
+    __shared__ uint32_t s_base[SHADE_NUM_CLASSES];                   // block's first index in each class queue
+    const Counters C{rp.max_depth};
+    const uint32_t n = bounce == 0 ? rp.n_paths : P.counters[C.live(bounce)];
+    const uint32_t* __restrict__ qin = P.live[bounce & 1];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_tiles = (n + BIN_TILE - 1) / BIN_TILE;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t base = tile * BIN_TILE + wave * (64 * BIN_ITEMS);
+        uint32_t cls[BIN_ITEMS];
+        uint32_t wave_count[SHADE_NUM_CLASSES];
+#pragma unroll
+        for (int c = 0; c < SHADE_NUM_CLASSES; ++c) wave_count[c] = 0;
+#pragma unroll
+        for (int k = 0; k < BIN_ITEMS; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            cls[k] = i < n ? (uint32_t)P.cls_q[i] : 0xFFu;
+#pragma unroll
+            for (int c = 0; c < SHADE_NUM_CLASSES; ++c) wave_count[c] += __popcll(__ballot(cls[k] == (uint32_t)c));
+        }
+        if (lane < SHADE_NUM_CLASSES) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < SHADE_NUM_CLASSES; ++c) mine = lane == (uint32_t)c ? wave_count[c] : mine;
+            s_wave[wave][lane] = mine;
+        }
+        __syncthreads();
+        if (threadIdx.x < SHADE_NUM_CLASSES) {
+            const uint32_t c = threadIdx.x;
+            uint32_t total = 0;
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+                const uint32_t cnt = s_wave[w][c];
+                s_wave[w][c] = total;
+                total += cnt;
+            }
+            s_base[c] = total ? atomicAdd(&P.counters[C.cls(bounce, c)], total) : 0u;
+        }
+        __syncthreads();
+        uint32_t run[SHADE_NUM_CLASSES];
+#pragma unroll
+        for (int c = 0; c < SHADE_NUM_CLASSES; ++c) run[c] = s_base[c] + s_wave[wave][c];
+#pragma unroll
+        for (int k = 0; k < BIN_ITEMS; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            const uint32_t slot = i < n ? (bounce == 0 ? i : qin[i]) : 0u;
+#pragma unroll
+            for (int c = 0; c < SHADE_NUM_CLASSES; ++c) {
+                const unsigned long long m = __ballot(cls[k] == (uint32_t)c);
+                if (cls[k] == (uint32_t)c) P.cls_queue[(size_t)c * P.capacity + run[c] + mbcnt_lt(m)] = slot;
+                run[c] += __popcll(m);
+            }
+        }
+        __syncthreads();  // s_wave / s_base are reused by the next tile
+    }
+}
+
+// ----------------------------------------------------------------------- shade
+// One wave = 64 consecutive entries of ONE class queue.  The virtual index space
+// is the concatenation of the class queues, each padded to a multiple of 64.
+// Survivors are appended to the next live queue with one atomic per block step.
+template <bool HAS_NOISE>
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParams rp, uint32_t bounce) {
+    __shared__ uint32_t s_cnt[2][WAVES_PER_BLOCK];
+    __shared__ uint32_t s_base[2];
+    // Perlin tables (9 KB each: 256 gradient vectors + 3 permutations) staged in LDS
+    constexpr int N_STAGED = HAS_NOISE ? 2 : 0;
+    __shared__ mirt_perlin s_perlin[HAS_NOISE ? N_STAGED : 1];
+    uint32_t n_staged = 0;
+    if (HAS_NOISE) {
+        n_staged = sc.perlins ? (uint32_t)N_STAGED : 0u;
+        // number of tables in the scene is not in DScene; the host passes at least
+        // N_STAGED readable tables when HAS_NOISE (it pads the array)
+        const uint32_t words = (uint32_t)(sizeof(mirt_perlin) / 4) * n_staged;
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.perlins);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_perlin);
+        for (uint32_t w = threadIdx.x; w < words; w += BLOCK) dst[w] = src[w];
+        __syncthreads();
+    }
+
+    const Counters C{rp.max_depth};
+    uint32_t cnt[SHADE_NUM_CLASSES], pref[SHADE_NUM_CLASSES + 1];
+    pref[0] = 0;
+#pragma unroll
+    for (int c = 0; c < SHADE_NUM_CLASSES; ++c) {
+        cnt[c] = P.counters[C.cls(bounce, c)];
+        pref[c + 1] = pref[c] + ((cnt[c] + 63u) >> 6);
+    }
+    const uint32_t total_chunks = pref[SHADE_NUM_CLASSES];
+    const bool last = bounce + 1 == rp.max_depth;
+    uint32_t* __restrict__ qout = P.live[(bounce + 1) & 1];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const V3 background = v3(rp.background[0], rp.background[1], rp.background[2]);
+
+    uint32_t it = 0;
+    for (uint32_t chunk0 = blockIdx.x * WAVES_PER_BLOCK; chunk0 < total_chunks;
+         chunk0 += gridDim.x * WAVES_PER_BLOCK, ++it) {
+        const uint32_t chunk = chunk0 + wave;
+        uint32_t cls = 0, first = 0;
+        bool valid = false;
+        if (chunk < total_chunks) {
+#pragma unroll
+            for (int c = 0; c < SHADE_NUM_CLASSES; ++c)
+                if (chunk >= pref[c] && chunk < pref[c + 1]) {
+                    cls = c;
+                    first = (chunk - pref[c]) * 64;
+                }
+            valid = first + lane < cnt[cls];
+        }
+        cls = __builtin_amdgcn_readfirstlane(cls);  // wave-uniform by construction
+        bool alive = false;
+        uint32_t slot = 0;
+        if (valid) {
+            slot = P.cls_queue[(size_t)cls * P.capacity + first + lane];
+            const V3 beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
+            V3 radiance = v3(0.0, 0.0, 0.0);
+            if (cls == SHADE_MISS) {
+                radiance = beta * background;  // renderer.rs:114
+            } else {
+                RayD r;
+                r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
+                r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
+                r.time = P.time[slot];
+                const uint32_t ref = P.hit_ref[slot];
+                const Surface h =
+                    surface_at(sc, r, P.hit_t[slot], ref & REF_INDEX_MASK, (int)(ref >> HIT_SIDE_SHIFT));
+                const mirt_material* __restrict__ m = sc.materials + h.material;
+                const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
+                if (cls == SHADE_LIGHT) {
+                    // material.rs:144-152: no scatter, emit = texture value
+                    radiance = beta * texture_value(sc, m->texture, h, lds_tables, n_staged);
+                } else if (!last) {
+                    // when this is the last bounce the path's value is multiplied by
+                    // color(.., 0) = 0 (renderer.rs:99-101): nothing to compute
+                    PathRng rng{P.stream[slot], bounce + 1u, 0u};
+                    V3 dir, attenuation;
+                    bool scattered = true;
+                    if (cls == SHADE_METAL) {  // material.rs:74-91
+                        const V3 reflected = reflect(unit(r.d), h.normal);
+                        dir = reflected + m->param * random_in_unit_sphere(rng);
+                        scattered = dot(dir, h.normal) > 0.0;
+                        attenuation = v3(m->albedo[0], m->albedo[1], m->albedo[2]);
+                    } else if (cls == SHADE_DIELECTRIC) {  // material.rs:104-131
+                        const double refraction_ratio = h.front_facing ? 1.0 / m->param : m->param;
+                        const V3 unit_direction = unit(r.d);
+                        const double cos_theta = fmin(dot(-unit_direction, h.normal), 1.0);
+                        const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                        const bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+                        if (cannot_refract || schlick(cos_theta, refraction_ratio) > rng.random_double()) {
+                            dir = reflect(unit_direction, h.normal);
+                        } else {
+                            dir = refract(unit_direction, h.normal, refraction_ratio);
+                        }
+                        attenuation = v3(1.0, 1.0, 1.0);
+                    } else {  // the lambertian classes, material.rs:51-59
+                        const V3 target = h.p + h.normal + random_in_unit_sphere(rng);
+                        dir = target - h.p;
+                        attenuation = texture_value(sc, m->texture, h, lds_tables, n_staged);
+                    }
+                    if (scattered) {
+                        alive = true;
+                        P.ox[slot] = h.p.x; P.oy[slot] = h.p.y; P.oz[slot] = h.p.z;
+                        P.dx[slot] = dir.x; P.dy[slot] = dir.y; P.dz[slot] = dir.z;
+                        // (emitted + attenuation) with emitted = 0, renderer.rs:107
+                        const V3 nb = beta * attenuation;
+                        P.bx[slot] = nb.x; P.by[slot] = nb.y; P.bz[slot] = nb.z;
+                    }
+                }
+            }
+            if (!alive) {
+                P.rr[slot] = radiance.x; P.rg[slot] = radiance.y; P.rb[slot] = radiance.z;
+            }
+        }
+        // ---- append survivors: ballot per wave, one atomic per block step
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t buf = it & 1;
+        if (lane == 0) s_cnt[buf][wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) total += s_cnt[buf][w];
+            s_base[buf] = total ? atomicAdd(&P.counters[C.live(bounce + 1)], total) : 0u;
+        }
+        __syncthreads();
+        if (alive) {
+            uint32_t off = s_base[buf];
+            for (uint32_t w = 0; w < wave; ++w) off += s_cnt[buf][w];
+            qout[off + mbcnt_lt(mask)] = slot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ accumulate
+// pixel += color(sample) for the samples of this pass, in sample order
+// (renderer.rs:78-84), into the caller's f64 accumulation image.
+__global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, double* __restrict__ accum) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < rp.n_pixels; k += stride) {
+        const size_t idx = (size_t)rp.pixel_begin + k;
+        double r = accum[3 * idx + 0], g = accum[3 * idx + 1], b = accum[3 * idx + 2];
+        for (uint32_t s = 0; s < rp.n_samples; ++s) {
+            const size_t slot = (size_t)s * rp.n_pixels + k;
+            r += P.rr[slot];
+            g += P.rg[slot];
+            b += P.rb[slot];
+        }
+        accum[3 * idx + 0] = r;
+        accum[3 * idx + 1] = g;
+        accum[3 * idx + 2] = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const Counters C{rp.max_depth};
+        unsigned long long seg = rp.n_paths;
+        for (uint32_t b = 1; b < rp.max_depth; ++b) seg += P.counters[C.live(b)];
+        *P.segments += seg;
+    }
+}
+
+// --------------------------------------------------------------------- resolve
+// renderer.rs:85-89 and the `as u8` of renderer.rs:42 (saturating, truncating, NaN -> 0).
+__device__ __forceinline__ uint8_t f64_as_u8(double x) {
+    if (x != x) return 0;
+    if (x <= 0.0) return 0;
+    if (x >= 255.0) return 255;
+    return (uint8_t)(int)x;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(const double* __restrict__ accum, uint32_t pixel_begin,
+                                                   uint32_t n_pixels, uint32_t spp, uint8_t* __restrict__ out) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    const double n = (double)spp;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n_pixels; k += stride) {
+        const size_t idx = (size_t)pixel_begin + k;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = accum[3 * idx + c] / n;
+            v = sqrt(v);
+            v = v * 255.99;
+            out[3 * (size_t)k + c] = f64_as_u8(v);
+        }
+    }
+}
+
+}  // namespace mirt

@@ -1,0 +1,754 @@
+// mirt.hip -- the C ABI of include/mirt.h over the gfx950 kernels of kernels.h:
+// scene validation + upload, the closest-hit entry points, and the pass loop
+// that replaces render_world (reference src/renderer.rs:9-62).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mirt.h"
+#include "kernels.h"
+
+using namespace mirt;
+
+// ------------------------------------------------------------------ errors
+namespace {
+thread_local std::string tl_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tl_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_HIP,       \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Frees a set of device allocations when it goes out of scope.
+struct DeviceArena {
+    std::vector<void*> ptrs;
+    ~DeviceArena() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+    void release() { ptrs.clear(); }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    int enter(int device) {
+        if (device < 0) return MIRT_OK;
+        if (hipGetDevice(&prev) != hipSuccess) return fail(MIRT_ERR_NO_DEVICE, "hipGetDevice failed: no HIP device");
+        if (prev != device) {
+            if (hipSetDevice(device) != hipSuccess) return fail(MIRT_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+            active = true;
+        }
+        return MIRT_OK;
+    }
+    ~DeviceGuard() {
+        if (active) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
+struct mirt_scene {
+    int device = 0;
+    DScene d{};
+    std::vector<void*> allocations;
+    uint32_t height = 0;        // levels of inner nodes on the longest root-to-leaf chain
+    bool has_bvh = false;
+    bool has_noise = false;
+    int cu_count = 0;
+};
+
+extern "C" {
+
+uint32_t mirt_abi_version(void) { return 1; }
+
+const char* mirt_last_error(void) { return tl_error.c_str(); }
+
+int mirt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------ scene create
+static uint32_t shade_class_of(const mirt_scene_desc* desc, const mirt_material& m) {
+    switch (m.kind) {
+        case MIRT_MAT_DIELECTRIC: return SHADE_DIELECTRIC;
+        case MIRT_MAT_METAL: return SHADE_METAL;
+        case MIRT_MAT_DIFFUSE_LIGHT: return SHADE_LIGHT;
+        default: break;
+    }
+    switch (desc->textures[m.texture].kind) {
+        case MIRT_TEX_CHECKER: return SHADE_LAMBERTIAN_CHECKER;
+        case MIRT_TEX_NOISE: return SHADE_LAMBERTIAN_NOISE;
+        case MIRT_TEX_IMAGE: return SHADE_LAMBERTIAN_IMAGE;
+        default: return SHADE_LAMBERTIAN_CONSTANT;
+    }
+}
+
+// Bounding box of a leaf child, stored in its parent only to order and
+// distance-prune (the reference never slab-tests a leaf).  A moving sphere is
+// boxed over its own [time_start, time_end].
+static void advisory_box(const mirt_shape& s, double lo[3], double hi[3]) {
+    auto sphere = [&](const double c[3], double r, double l[3], double h[3]) {
+        const double a = std::fabs(r);
+        for (int k = 0; k < 3; ++k) {
+            l[k] = c[k] - a;
+            h[k] = c[k] + a;
+        }
+    };
+    const double pad = 0.0001;
+    switch (s.kind) {
+        case MIRT_SHAPE_SPHERE: sphere(s.f, s.f[3], lo, hi); break;
+        case MIRT_SHAPE_MOVING_SPHERE: {
+            double l2[3], h2[3];
+            sphere(s.f, s.f[3], lo, hi);
+            sphere(s.f + 4, s.f[3], l2, h2);
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::fmin(lo[k], l2[k]);
+                hi[k] = std::fmax(hi[k], h2[k]);
+            }
+            break;
+        }
+        case MIRT_SHAPE_XY_RECT:
+            lo[0] = s.f[0]; hi[0] = s.f[1]; lo[1] = s.f[2]; hi[1] = s.f[3]; lo[2] = s.f[4] - pad; hi[2] = s.f[4] + pad;
+            break;
+        case MIRT_SHAPE_XZ_RECT:
+            lo[0] = s.f[0]; hi[0] = s.f[1]; lo[2] = s.f[2]; hi[2] = s.f[3]; lo[1] = s.f[4] - pad; hi[1] = s.f[4] + pad;
+            break;
+        case MIRT_SHAPE_YZ_RECT:
+            lo[1] = s.f[0]; hi[1] = s.f[1]; lo[2] = s.f[2]; hi[2] = s.f[3]; lo[0] = s.f[4] - pad; hi[0] = s.f[4] + pad;
+            break;
+        default:  // cube
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::fmin(s.f[k], s.f[3 + k]) - pad;
+                hi[k] = std::fmax(s.f[k], s.f[3 + k]) + pad;
+            }
+            break;
+    }
+}
+
+static int validate_desc(const mirt_scene_desc* d) {
+    if (!d) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene description is null");
+    if (!d->shapes || d->n_shapes == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene has no shapes");
+    if (d->n_shapes > MAX_SHAPES) return fail(MIRT_ERR_UNSUPPORTED, "more than %u shapes", MAX_SHAPES);
+    if (!d->materials || d->n_materials == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene has no materials");
+    if (d->n_textures && !d->textures) return fail(MIRT_ERR_INVALID_ARGUMENT, "textures is null");
+    if (d->n_perlins && !d->perlins) return fail(MIRT_ERR_INVALID_ARGUMENT, "perlins is null");
+    if (d->n_images && !d->images) return fail(MIRT_ERR_INVALID_ARGUMENT, "images is null");
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const mirt_texture& t = d->textures[i];
+        switch (t.kind) {
+            case MIRT_TEX_CONSTANT: break;
+            case MIRT_TEX_CHECKER:
+                // children must precede the parent: keeps the texture graph acyclic
+                if (t.even >= i || t.odd >= i)
+                    return fail(MIRT_ERR_INVALID_ARGUMENT, "texture %u: checker children must have smaller indices", i);
+                break;
+            case MIRT_TEX_NOISE:
+                if (t.perlin >= d->n_perlins) return fail(MIRT_ERR_INVALID_ARGUMENT, "texture %u: bad perlin index", i);
+                break;
+            case MIRT_TEX_IMAGE:
+                if (t.image >= d->n_images) return fail(MIRT_ERR_INVALID_ARGUMENT, "texture %u: bad image index", i);
+                break;
+            default: return fail(MIRT_ERR_INVALID_ARGUMENT, "texture %u: unknown kind %u", i, t.kind);
+        }
+    }
+    for (uint32_t i = 0; i < d->n_perlins; ++i)
+        for (int k = 0; k < 256; ++k) {
+            const mirt_perlin& p = d->perlins[i];
+            if ((uint32_t)p.perm_x[k] > 255u || (uint32_t)p.perm_y[k] > 255u || (uint32_t)p.perm_z[k] > 255u)
+                return fail(MIRT_ERR_INVALID_ARGUMENT, "perlin %u: permutation entry out of 0..255", i);
+        }
+    for (uint32_t i = 0; i < d->n_images; ++i)
+        if (!d->images[i].rgb || d->images[i].width == 0 || d->images[i].height == 0)
+            return fail(MIRT_ERR_INVALID_ARGUMENT, "image %u: empty", i);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const mirt_material& m = d->materials[i];
+        if (m.kind > MIRT_MAT_DIFFUSE_LIGHT) return fail(MIRT_ERR_INVALID_ARGUMENT, "material %u: unknown kind %u", i, m.kind);
+        if ((m.kind == MIRT_MAT_LAMBERTIAN || m.kind == MIRT_MAT_DIFFUSE_LIGHT) && m.texture >= d->n_textures)
+            return fail(MIRT_ERR_INVALID_ARGUMENT, "material %u: bad texture index", i);
+    }
+    for (uint32_t i = 0; i < d->n_shapes; ++i) {
+        const mirt_shape& s = d->shapes[i];
+        if (s.kind > MIRT_SHAPE_MOVING_SPHERE) return fail(MIRT_ERR_INVALID_ARGUMENT, "shape %u: unknown kind %u", i, s.kind);
+        if (s.material >= d->n_materials) return fail(MIRT_ERR_INVALID_ARGUMENT, "shape %u: bad material index", i);
+    }
+    if (d->nodes) {
+        if (d->n_nodes != 2 * d->n_shapes - 1)
+            return fail(MIRT_ERR_INVALID_ARGUMENT, "BVH has %u members, expected 2n-1 = %u", d->n_nodes, 2 * d->n_shapes - 1);
+        std::vector<uint8_t> shape_seen(d->n_shapes, 0), member_used(d->n_nodes, 0);
+        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+            const mirt_bvh_member& m = d->nodes[i];
+            if (m.is_leaf) {
+                if (m.shape >= d->n_shapes || shape_seen[m.shape])
+                    return fail(MIRT_ERR_INVALID_ARGUMENT, "BVH member %u: bad or repeated shape index", i);
+                shape_seen[m.shape] = 1;
+            } else {
+                // post-order: children precede their parent (bvh.rs:204-236)
+                if (m.left >= i || m.right >= i || m.left == m.right || member_used[m.left] || member_used[m.right])
+                    return fail(MIRT_ERR_INVALID_ARGUMENT, "BVH member %u: children must be distinct, unshared earlier members", i);
+                member_used[m.left] = member_used[m.right] = 1;
+            }
+        }
+        for (uint32_t i = 0; i + 1 < d->n_nodes; ++i)
+            if (!member_used[i]) return fail(MIRT_ERR_INVALID_ARGUMENT, "BVH member %u is not reachable from the root", i);
+    }
+    return MIRT_OK;
+}
+
+int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out) {
+    if (!out) return fail(MIRT_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc != MIRT_OK) return rc;
+    if (mirt_device_count() == 0) return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible");
+    DeviceGuard guard;
+    if ((rc = guard.enter(device)) != MIRT_OK) return rc;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+
+    // ---- host-side flattening
+    std::vector<DShape> shapes(desc->n_shapes);
+    bool has_noise = false;
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        const mirt_shape& s = desc->shapes[i];
+        std::memset(&shapes[i], 0, sizeof(DShape));
+        std::memcpy(shapes[i].f, s.f, sizeof s.f);
+        shapes[i].kind = s.kind;
+        shapes[i].material = s.material;
+        shapes[i].cls = shade_class_of(desc, desc->materials[s.material]);
+    }
+    for (uint32_t i = 0; i < desc->n_textures; ++i) has_noise |= desc->textures[i].kind == MIRT_TEX_NOISE;
+
+    std::vector<DNode> nodes;
+    uint32_t root_ref = 0, height = 0;
+    if (desc->nodes) {
+        const uint32_t nm = desc->n_nodes;
+        auto leaf_ref = [&](const mirt_bvh_member& m) {
+            return REF_LEAF | (desc->shapes[m.shape].kind << REF_KIND_SHIFT) | m.shape;
+        };
+        const mirt_bvh_member& root = desc->nodes[nm - 1];
+        if (root.is_leaf) {
+            root_ref = leaf_ref(root);
+        } else {
+            // breadth-first numbering from the root: the levels every ray visits sit together
+            std::vector<uint32_t> order;  // member index of node k
+            std::vector<uint32_t> node_of(nm, 0xFFFFFFFFu), level(nm, 0);
+            order.push_back(nm - 1);
+            node_of[nm - 1] = 0;
+            level[nm - 1] = 1;
+            for (size_t k = 0; k < order.size(); ++k) {
+                const mirt_bvh_member& m = desc->nodes[order[k]];
+                height = std::max(height, level[order[k]]);
+                for (uint32_t child : {m.left, m.right})
+                    if (!desc->nodes[child].is_leaf) {
+                        node_of[child] = (uint32_t)order.size();
+                        level[child] = level[order[k]] + 1;
+                        order.push_back(child);
+                    }
+            }
+            nodes.resize(order.size());
+            for (size_t k = 0; k < order.size(); ++k) {
+                const mirt_bvh_member& m = desc->nodes[order[k]];
+                DNode& n = nodes[k];
+                std::memset(&n, 0, sizeof n);
+                const uint32_t kids[2] = {m.left, m.right};
+                for (int c = 0; c < 2; ++c) {
+                    const mirt_bvh_member& ch = desc->nodes[kids[c]];
+                    double lo[3], hi[3];
+                    if (ch.is_leaf) {
+                        n.child[c] = leaf_ref(ch);
+                        advisory_box(desc->shapes[ch.shape], lo, hi);
+                    } else {
+                        n.child[c] = node_of[kids[c]];
+                        std::memcpy(lo, ch.bmin, sizeof lo);
+                        std::memcpy(hi, ch.bmax, sizeof hi);
+                    }
+                    for (int a = 0; a < 3; ++a) {
+                        n.box[c][a][0] = lo[a];
+                        n.box[c][a][1] = hi[a];
+                    }
+                }
+            }
+            root_ref = 0;
+        }
+        if (height + 1 > (uint32_t)MAX_TREE_HEIGHT)
+            return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", height + 1, MAX_TREE_HEIGHT);
+    }
+
+    // ---- upload
+    auto* sc = new (std::nothrow) mirt_scene();
+    if (!sc) return fail(MIRT_ERR_OUT_OF_MEMORY, "out of host memory");
+    sc->device = dev;
+    sc->has_bvh = desc->nodes != nullptr;
+    sc->has_noise = has_noise;
+    sc->height = height;
+    DeviceArena arena;
+    auto upload = [&](auto** dptr, const auto* src, size_t count, size_t min_count = 1) -> hipError_t {
+        using T = std::remove_const_t<std::remove_pointer_t<decltype(src)>>;
+        T* p = nullptr;
+        hipError_t e = arena.alloc(&p, std::max(count, min_count));
+        if (e != hipSuccess) return e;
+        if (std::max(count, min_count) > count) {
+            e = hipMemset(p, 0, std::max(count, min_count) * sizeof(T));
+            if (e != hipSuccess) return e;
+        }
+        if (count) e = hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+        *dptr = p;
+        return e;
+    };
+#define SCENE_TRY(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            delete sc;                                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                                    \
+        }                                                                                                 \
+    } while (0)
+    DShape* d_shapes = nullptr;
+    DNode* d_nodes = nullptr;
+    mirt_bvh_member* d_members = nullptr;
+    mirt_material* d_materials = nullptr;
+    mirt_texture* d_textures = nullptr;
+    mirt_perlin* d_perlins = nullptr;
+    mirt_image* d_images = nullptr;
+    SCENE_TRY(upload(&d_shapes, shapes.data(), shapes.size()));
+    SCENE_TRY(upload(&d_nodes, nodes.data(), nodes.size()));
+    SCENE_TRY(upload(&d_members, desc->nodes, desc->nodes ? desc->n_nodes : 0));
+    SCENE_TRY(upload(&d_materials, desc->materials, desc->n_materials));
+    SCENE_TRY(upload(&d_textures, desc->textures, desc->n_textures));
+    // the shade kernel stages the first two Perlin tables into LDS: keep two readable
+    SCENE_TRY(upload(&d_perlins, desc->perlins, desc->n_perlins, 2));
+    std::vector<mirt_image> images(desc->n_images);
+    for (uint32_t i = 0; i < desc->n_images; ++i) {
+        images[i] = desc->images[i];
+        uint8_t* d_rgb = nullptr;
+        SCENE_TRY(upload(&d_rgb, desc->images[i].rgb, (size_t)images[i].width * images[i].height * 3));
+        images[i].rgb = d_rgb;
+    }
+    SCENE_TRY(upload(&d_images, images.data(), images.size()));
+#undef SCENE_TRY
+    sc->d.shapes = d_shapes;
+    sc->d.nodes = d_nodes;
+    sc->d.members = d_members;
+    sc->d.materials = d_materials;
+    sc->d.textures = d_textures;
+    sc->d.perlins = d_perlins;
+    sc->d.images = d_images;
+    sc->d.n_shapes = desc->n_shapes;
+    sc->d.n_members = desc->nodes ? desc->n_nodes : 0;
+    sc->d.n_nodes = (uint32_t)nodes.size();
+    sc->d.root_ref = root_ref;
+    if (desc->nodes && !desc->nodes[desc->n_nodes - 1].is_leaf) {
+        const mirt_bvh_member& root = desc->nodes[desc->n_nodes - 1];
+        for (int a = 0; a < 3; ++a) {
+            sc->d.root_box[a][0] = root.bmin[a];
+            sc->d.root_box[a][1] = root.bmax[a];
+        }
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) sc->cu_count = prop.multiProcessorCount;
+    if (sc->cu_count <= 0) sc->cu_count = 256;
+    sc->allocations = arena.ptrs;
+    arena.release();
+    *out = sc;
+    return MIRT_OK;
+}
+
+void mirt_scene_destroy(mirt_scene* scene) {
+    if (!scene) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != scene->device) (void)hipSetDevice(scene->device);
+    for (void* p : scene->allocations) (void)hipFree(p);
+    if (prev >= 0 && prev != scene->device) (void)hipSetDevice(prev);
+    delete scene;
+}
+
+// -------------------------------------------------------------- intersect
+static int pick_mode(const mirt_scene* scene, int use_bvh, int traversal, int* mode) {
+    if (!use_bvh) {
+        *mode = MODE_LIST;
+        return MIRT_OK;
+    }
+    if (!scene->has_bvh) return fail(MIRT_ERR_INVALID_ARGUMENT, "use_bvh = 1 but the scene was created without BVH members");
+    if (traversal == MIRT_TRAVERSE_REFERENCE) *mode = MODE_REFERENCE;
+    else if (traversal == MIRT_TRAVERSE_FAST) *mode = MODE_FAST;
+    else return fail(MIRT_ERR_INVALID_ARGUMENT, "unknown traversal mode %d", traversal);
+    return MIRT_OK;
+}
+
+static int grid_for(const mirt_scene* scene, size_t work_items, int blocks_per_cu) {
+    const size_t want = (work_items + BLOCK - 1) / BLOCK;
+    const size_t cap = (size_t)scene->cu_count * (size_t)blocks_per_cu;
+    return (int)std::max<size_t>(1, std::min(want, cap));
+}
+
+int mirt_intersect_device(const mirt_scene* scene, const mirt_ray* d_rays, size_t n, double t_min, double t_max,
+                          int use_bvh, int traversal, mirt_hit* d_hits) {
+    if (!scene) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n == 0) return MIRT_OK;
+    if (!d_rays || !d_hits) return fail(MIRT_ERR_INVALID_ARGUMENT, "rays or hits is null");
+    int mode = 0, rc = pick_mode(scene, use_bvh, traversal, &mode);
+    if (rc != MIRT_OK) return rc;
+    DeviceGuard guard;
+    if ((rc = guard.enter(scene->device)) != MIRT_OK) return rc;
+    const int grid = grid_for(scene, n, 8);
+    switch (mode) {
+        case MODE_LIST: hipLaunchKernelGGL(k_intersect<MODE_LIST>, dim3(grid), dim3(BLOCK), 0, 0, scene->d, d_rays, n, t_min, t_max, d_hits); break;
+        case MODE_REFERENCE: hipLaunchKernelGGL(k_intersect<MODE_REFERENCE>, dim3(grid), dim3(BLOCK), 0, 0, scene->d, d_rays, n, t_min, t_max, d_hits); break;
+        default: hipLaunchKernelGGL(k_intersect<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, 0, scene->d, d_rays, n, t_min, t_max, d_hits); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
+    return MIRT_OK;
+}
+
+int mirt_intersect(const mirt_scene* scene, const mirt_ray* rays, size_t n, double t_min, double t_max, int use_bvh,
+                   int traversal, mirt_hit* hits) {
+    if (!scene) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n == 0) return MIRT_OK;
+    if (!rays || !hits) return fail(MIRT_ERR_INVALID_ARGUMENT, "rays or hits is null");
+    int mode = 0, rc = pick_mode(scene, use_bvh, traversal, &mode);
+    if (rc != MIRT_OK) return rc;
+    DeviceGuard guard;
+    if ((rc = guard.enter(scene->device)) != MIRT_OK) return rc;
+    DeviceArena arena;
+    mirt_ray* d_rays = nullptr;
+    mirt_hit* d_hits = nullptr;
+    HIP_TRY(arena.alloc(&d_rays, n));
+    HIP_TRY(arena.alloc(&d_hits, n));
+    HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(mirt_ray), hipMemcpyHostToDevice));
+    rc = mirt_intersect_device(scene, d_rays, n, t_min, t_max, use_bvh, traversal, d_hits);
+    if (rc != MIRT_OK) return rc;
+    HIP_TRY(hipMemcpy(hits, d_hits, n * sizeof(mirt_hit), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+int mirt_camera_rays(const mirt_camera* camera, uint32_t width, uint32_t height, uint32_t pixel_begin,
+                     uint32_t pixel_end, uint32_t sample, uint64_t seed, int device, mirt_ray* rays) {
+    if (!camera || !rays) return fail(MIRT_ERR_INVALID_ARGUMENT, "camera or rays is null");
+    if (width == 0 || height == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image");
+    if (pixel_end == 0) pixel_end = width * height;
+    if (pixel_begin >= pixel_end || pixel_end > width * height) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad pixel range");
+    if (mirt_device_count() == 0) return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible");
+    DeviceGuard guard;
+    int rc = guard.enter(device);
+    if (rc != MIRT_OK) return rc;
+    const uint32_t n = pixel_end - pixel_begin;
+    DeviceArena arena;
+    mirt_ray* d_rays = nullptr;
+    HIP_TRY(arena.alloc(&d_rays, (size_t)n));
+    const int grid = (int)std::min<size_t>(((size_t)n + BLOCK - 1) / BLOCK, 4096);
+    hipLaunchKernelGGL(k_camera_rays, dim3(grid), dim3(BLOCK), 0, 0, *camera, width, height, pixel_begin, n, sample, seed, d_rays);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rays, d_rays, (size_t)n * sizeof(mirt_ray), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ render
+namespace {
+
+struct EventTimer {
+    // Pairs of HIP events around kernel launches of one pass, summed per class after the pass.
+    enum Class { RAYGEN = 0, EXTEND, BIN, SHADE, ACCUMULATE, N_CLASSES };
+    bool enabled = false;
+    std::vector<hipEvent_t> pool;
+    std::vector<int> cls_of_pair;
+    size_t used = 0;
+    double ms[N_CLASSES] = {0, 0, 0, 0, 0};
+
+    hipError_t begin(hipStream_t s, int cls) {
+        if (!enabled) return hipSuccess;
+        while (pool.size() < used + 2) {
+            hipEvent_t e;
+            hipError_t err = hipEventCreate(&e);
+            if (err != hipSuccess) return err;
+            pool.push_back(e);
+        }
+        cls_of_pair.push_back(cls);
+        return hipEventRecord(pool[used], s);
+    }
+    hipError_t end(hipStream_t s) {
+        if (!enabled) return hipSuccess;
+        hipError_t err = hipEventRecord(pool[used + 1], s);
+        used += 2;
+        return err;
+    }
+    hipError_t collect() {  // call after the stream has been synchronised
+        if (!enabled) return hipSuccess;
+        for (size_t p = 0; p < used / 2; ++p) {
+            float t = 0.f;
+            hipError_t err = hipEventElapsedTime(&t, pool[2 * p], pool[2 * p + 1]);
+            if (err != hipSuccess) return err;
+            ms[cls_of_pair[p]] += t;
+        }
+        used = 0;
+        cls_of_pair.clear();
+        return hipSuccess;
+    }
+    ~EventTimer() {
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+template <class K>
+int blocks_per_cu(K kernel, int fallback) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0) != hipSuccess || n <= 0) return fallback;
+    return std::min(n, 8);
+}
+
+int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
+                           uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
+                           const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {
+    if (!scene || !camera || !background || !d_accum) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (width == 0 || height == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image");
+    if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^31 pixels");
+    if (spp == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "spp must be > 0");
+    if (max_depth == 0 || max_depth > 255) return fail(MIRT_ERR_INVALID_ARGUMENT, "max_depth must be in 1..255 (the reference's is a u8)");
+    mirt_render_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.device = -1;
+    o.use_bvh = 1;
+    o.traversal = MIRT_TRAVERSE_FAST;
+    if (opts) {
+        if (opts->struct_size != sizeof(mirt_render_opts))
+            return fail(MIRT_ERR_INVALID_ARGUMENT, "mirt_render_opts.struct_size is %u, expected %zu", opts->struct_size, sizeof(mirt_render_opts));
+        o = *opts;
+    }
+    const uint32_t n_pix_total = width * height;
+    if (o.pixel_end == 0) o.pixel_end = n_pix_total;
+    if (o.sample_end == 0) o.sample_end = spp;
+    if (o.pixel_begin >= o.pixel_end || o.pixel_end > n_pix_total) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad pixel range");
+    if (o.sample_begin >= o.sample_end || o.sample_end > spp) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad sample range");
+    if (o.device >= 0 && o.device != scene->device)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "opts.device = %d but the scene lives on device %d", o.device, scene->device);
+    int mode = 0, rc = pick_mode(scene, o.use_bvh, o.traversal, &mode);
+    if (rc != MIRT_OK) return rc;
+    DeviceGuard guard;
+    if ((rc = guard.enter(scene->device)) != MIRT_OK) return rc;
+
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint32_t n_pixels = o.pixel_end - o.pixel_begin;
+    const uint32_t n_samples_total = o.sample_end - o.sample_begin;
+    const uint64_t target = o.paths_per_pass ? o.paths_per_pass : (1ull << 23);
+    uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, target / n_pixels));
+    const uint64_t capacity64 = (uint64_t)n_pixels * per_pass;
+    if (capacity64 > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "pass of %llu paths is too large", (unsigned long long)capacity64);
+    const uint32_t capacity = (uint32_t)capacity64;
+
+    // ---- per-pass state
+    DeviceArena arena;
+    Paths P;
+    std::memset(&P, 0, sizeof P);
+    P.capacity = capacity;
+    double** f64_arrays[] = {&P.ox, &P.oy, &P.oz, &P.dx, &P.dy, &P.dz, &P.time, &P.bx, &P.by, &P.bz, &P.hit_t, &P.rr, &P.rg, &P.rb};
+    for (double** a : f64_arrays) HIP_TRY(arena.alloc(a, (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.hit_ref, (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.stream, (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.live[0], (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.live[1], (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.cls_q, (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.cls_queue, (size_t)capacity * SHADE_NUM_CLASSES));
+    const Counters C{max_depth};
+    HIP_TRY(arena.alloc(&P.counters, (size_t)C.total()));
+    HIP_TRY(arena.alloc(&P.segments, (size_t)1));
+    hipStream_t stream = 0;
+    HIP_TRY(hipMemsetAsync(P.segments, 0, sizeof(unsigned long long), stream));
+
+    RenderParams rp;
+    std::memset(&rp, 0, sizeof rp);
+    rp.cam = *camera;
+    for (int c = 0; c < 3; ++c) rp.background[c] = background[c];
+    rp.width = width;
+    rp.height = height;
+    rp.max_depth = max_depth;
+    rp.pixel_begin = o.pixel_begin;
+    rp.n_pixels = n_pixels;
+    rp.seed = seed;
+    rp.t_min = 0.001;
+    rp.t_max = std::numeric_limits<double>::infinity();
+    rp.use_bvh = o.use_bvh;
+    rp.traversal = o.traversal;
+
+    int occ_extend = 4;
+    switch (mode) {
+        case MODE_LIST: occ_extend = blocks_per_cu(k_extend<MODE_LIST>, 4); break;
+        case MODE_REFERENCE: occ_extend = blocks_per_cu(k_extend<MODE_REFERENCE>, 2); break;
+        default: occ_extend = blocks_per_cu(k_extend<MODE_FAST>, 4); break;
+    }
+    const int occ_shade = scene->has_noise ? blocks_per_cu(k_shade<true>, 2) : blocks_per_cu(k_shade<false>, 4);
+
+    EventTimer timer;
+    timer.enabled = o.profile != 0;
+    uint64_t passes = 0, launches_extend = 0, launches_shade = 0;
+
+    for (uint32_t s0 = o.sample_begin; s0 < o.sample_end; s0 += per_pass) {
+        rp.sample_base = s0;
+        rp.n_samples = std::min(per_pass, o.sample_end - s0);
+        rp.n_paths = n_pixels * rp.n_samples;
+        HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)C.total() * sizeof(uint32_t), stream));
+
+        HIP_TRY(timer.begin(stream, EventTimer::RAYGEN));
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(scene, rp.n_paths, 8)), dim3(BLOCK), 0, stream, P, rp);
+        HIP_TRY(timer.end(stream));
+
+        const int grid_extend = grid_for(scene, rp.n_paths, occ_extend);
+        const int grid_shade = grid_for(scene, rp.n_paths, occ_shade);
+        const int grid_bin = (int)std::max<size_t>(1, std::min<size_t>(((size_t)rp.n_paths + BIN_TILE - 1) / BIN_TILE, (size_t)scene->cu_count * 8));
+        for (uint32_t bounce = 0; bounce < max_depth; ++bounce) {
+            HIP_TRY(timer.begin(stream, EventTimer::EXTEND));
+            switch (mode) {
+                case MODE_LIST: hipLaunchKernelGGL(k_extend<MODE_LIST>, dim3(grid_extend), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce); break;
+                case MODE_REFERENCE: hipLaunchKernelGGL(k_extend<MODE_REFERENCE>, dim3(grid_extend), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce); break;
+                default: hipLaunchKernelGGL(k_extend<MODE_FAST>, dim3(grid_extend), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce); break;
+            }
+            HIP_TRY(timer.end(stream));
+            HIP_TRY(timer.begin(stream, EventTimer::BIN));
+            hipLaunchKernelGGL(k_bin, dim3(grid_bin), dim3(BLOCK), 0, stream, P, rp, bounce);
+            HIP_TRY(timer.end(stream));
+            HIP_TRY(timer.begin(stream, EventTimer::SHADE));
+            if (scene->has_noise) hipLaunchKernelGGL(k_shade<true>, dim3(grid_shade), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(grid_shade), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce);
+            HIP_TRY(timer.end(stream));
+            ++launches_extend;
+            ++launches_shade;
+        }
+        HIP_TRY(timer.begin(stream, EventTimer::ACCUMULATE));
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(scene, n_pixels, 8)), dim3(BLOCK), 0, stream, P, rp, d_accum);
+        HIP_TRY(timer.end(stream));
+        HIP_TRY(hipGetLastError());
+        if (timer.enabled) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(timer.collect());
+        }
+        ++passes;
+    }
+    unsigned long long segments = 0;
+    HIP_TRY(hipMemcpyAsync(&segments, P.segments, sizeof segments, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->samples = (uint64_t)n_pixels * n_samples_total;
+        stats->segments = segments;
+        stats->passes = passes;
+        stats->launches_extend = launches_extend;
+        stats->launches_shade = launches_shade;
+        stats->ms_raygen = timer.ms[EventTimer::RAYGEN];
+        stats->ms_extend = timer.ms[EventTimer::EXTEND];
+        stats->ms_bin = timer.ms[EventTimer::BIN];
+        stats->ms_shade = timer.ms[EventTimer::SHADE];
+        stats->ms_accumulate = timer.ms[EventTimer::ACCUMULATE];
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    }
+    return MIRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
+                           uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
+                           const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {
+    return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats);
+}
+
+int mirt_resolve(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
+                 uint32_t pixel_end, int device, uint8_t* out_rgb) {
+    if (!d_accum || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (width == 0 || height == 0 || spp == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image or spp = 0");
+    if (pixel_end == 0) pixel_end = width * height;
+    if (pixel_begin >= pixel_end || pixel_end > width * height) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad pixel range");
+    if (mirt_device_count() == 0) return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible");
+    DeviceGuard guard;
+    int rc = guard.enter(device);
+    if (rc != MIRT_OK) return rc;
+    const uint32_t n = pixel_end - pixel_begin;
+    DeviceArena arena;
+    uint8_t* d_out = nullptr;
+    HIP_TRY(arena.alloc(&d_out, (size_t)n * 3));
+    const int grid = (int)std::min<size_t>(((size_t)n + BLOCK - 1) / BLOCK, 4096);
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, 0, d_accum, pixel_begin, n, spp, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_rgb + (size_t)pixel_begin * 3, d_out, (size_t)n * 3, hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+int mirt_render(const mirt_scene* scene, const mirt_camera* camera, const double background[3], uint32_t width,
+                uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
+                uint8_t* out_rgb, mirt_stats* stats) {
+    if (!scene || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (opts && opts->struct_size == sizeof(mirt_render_opts) && (opts->sample_begin != 0 || (opts->sample_end != 0 && opts->sample_end != spp)))
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "mirt_render needs the whole sample range; use mirt_render_accumulate + mirt_resolve to split by samples");
+    if (width == 0 || height == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image");
+    const auto t_start = std::chrono::steady_clock::now();
+    DeviceGuard guard;
+    int rc = guard.enter(scene->device);
+    if (rc != MIRT_OK) return rc;
+    DeviceArena arena;
+    double* d_accum = nullptr;
+    const size_t n_values = (size_t)width * height * 3;
+    HIP_TRY(arena.alloc(&d_accum, n_values));
+    HIP_TRY(hipMemsetAsync(d_accum, 0, n_values * sizeof(double), 0));
+    rc = render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats);
+    if (rc != MIRT_OK) return rc;
+    const uint32_t pb = opts ? opts->pixel_begin : 0, pe = opts ? opts->pixel_end : 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = opts && opts->profile && stats;
+    if (prof) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, 0));
+    }
+    rc = mirt_resolve(d_accum, width, height, spp, pb, pe, scene->device, out_rgb);
+    if (prof) {
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        stats->ms_resolve = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    if (rc != MIRT_OK) return rc;
+    if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    return MIRT_OK;
+}
+
+}  // extern "C"

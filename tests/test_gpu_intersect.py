@@ -1,0 +1,95 @@
+"""Closest-hit parity on identical rays: the HIP traversals (reference order, fast
+order, linear list) against the CPU oracle.  Bar: hit/miss, primitive id and cube
+side bit-exact; t bit-exact too (the arithmetic is the same f64 sequence), with
+the 1e-5 relative bound of the north star kept as the stated tolerance."""
+import numpy as np
+import pytest
+
+from ray_tracer_amd import _abi as abi
+from ray_tracer_amd import api, configs
+
+pytestmark = pytest.mark.gpu
+
+T_REL_TOL = 1e-5
+
+
+def _ray_set(oracle, world, cfg, width, height, n_pixels=1500, samples=2):
+    """Primary + secondary rays: everything the oracle traces for a spread of pixels."""
+    cam = cfg.camera(width, height)
+    rng = np.random.default_rng(7)
+    pixels = rng.choice(width * height, size=min(n_pixels, width * height), replace=False).astype(np.uint32)
+    rays, hits = oracle.trace_rays(world.desc, cam, cfg.background, width, height, pixels, (0, samples))
+    return rays, hits
+
+
+def _compare(gpu, ref, what):
+    miss_g, miss_r = gpu["prim"] < 0, ref["prim"] < 0
+    assert np.array_equal(miss_g, miss_r), f"{what}: hit/miss differs on {np.count_nonzero(miss_g != miss_r)} rays"
+    assert np.array_equal(gpu["prim"], ref["prim"]), f"{what}: primitive id differs on {np.count_nonzero(gpu['prim'] != ref['prim'])} rays"
+    assert np.array_equal(gpu["side"], ref["side"]), f"{what}: cube side differs"
+    h = ~miss_r
+    rel = np.abs(gpu["t"][h] - ref["t"][h]) / np.abs(ref["t"][h])
+    assert rel.size == 0 or rel.max() <= T_REL_TOL, f"{what}: t off by {rel.max()}"
+    # same arithmetic, same bits
+    assert np.array_equal(gpu["t"][h], ref["t"][h]), f"{what}: t not bit-identical on {np.count_nonzero(gpu['t'][h] != ref['t'][h])} rays"
+
+
+@pytest.mark.parametrize("name", ["C1", "C3", "C4", "C5"])
+def test_bvh_traversals_match_oracle(name, worlds, oracle):
+    cfg = configs.ALL[name]
+    world = worlds(name)
+    rays, ref = _ray_set(oracle, world, cfg, 160, 90)
+    assert rays.shape[0] > 3000
+    scene = api.Scene(world)
+    try:
+        for trav, label in ((abi.TRAVERSE_REFERENCE, "reference-order"), (abi.TRAVERSE_FAST, "fast")):
+            gpu = scene.hit(rays, use_bvh=True, traversal=trav)
+            _compare(gpu, ref, f"{name} {label}")
+    finally:
+        scene.close()
+
+
+@pytest.mark.parametrize("name", ["C1", "C4", "Basic", "SimpleLight"])
+def test_linear_list_matches_oracle(name, worlds, oracle):
+    cfg = configs.ALL.get(name, configs.C1)
+    world = worlds(name)
+    cam = cfg.camera(96, 54)
+    rays = np.concatenate([api.camera_rays(cam, 96, 54, sample=s) for s in range(2)])
+    ref, _ = oracle.intersect(world.desc, rays, use_bvh=False)
+    scene = api.Scene(world)
+    try:
+        gpu = scene.hit(rays, use_bvh=False)
+        _compare(gpu, ref, f"{name} list")
+    finally:
+        scene.close()
+
+
+@pytest.mark.parametrize("name", ["Basic", "Checker", "Perlin", "Earth", "SimpleLight", "CornellBox"])
+def test_reference_scenes_bvh(name, worlds, oracle):
+    """The reference's own small scenes, including the one-shape world whose root is a leaf."""
+    world = worlds(name)
+    look = {"CornellBox": ((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 40.0)}.get(name, ((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0))
+    cam = api.Camera.new(look[0], look[1], (0, 1, 0), look[2], 16 / 9, 0.1, 10.0, 0.0, 1.0)
+    pixels = np.arange(0, 128 * 72, 5, dtype=np.uint32)
+    rays, ref = oracle.trace_rays(world.desc, cam, api.SKY, 128, 72, pixels, (0, 1))
+    scene = api.Scene(world)
+    try:
+        for trav in (abi.TRAVERSE_REFERENCE, abi.TRAVERSE_FAST):
+            _compare(scene.hit(rays, traversal=trav), ref, f"{name} traversal {trav}")
+    finally:
+        scene.close()
+
+
+def test_camera_rays_match_oracle(oracle):
+    import ctypes as C
+
+    cfg = configs.C1
+    cam = cfg.camera(64, 36)
+    gpu = api.camera_rays(cam, 64, 36, sample=3, seed=99)
+    ref = np.zeros(64 * 36, dtype=api.RAY_DTYPE)
+    r = abi.Ray()
+    for idx in range(64 * 36):
+        oracle.lib().oracle_camera_ray(C.byref(cam.c), 64, 36, idx, 3, 99, C.byref(r))
+        ref[idx] = (tuple(r.origin), tuple(r.direction), r.time)
+    for f in ("origin", "direction", "time"):
+        assert np.array_equal(gpu[f], ref[f]), f
