@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full render of the configuration (default C2: the RTIOW random-sphere
+scene at 1200x800, 500 spp, depth 50) through the C ABI (mirt_render), scene already
+resident in HBM.  Metric: Msamples/s = width * height * spp * steps / seconds, whole
+job.  With N > 1 (one process per GPU, launched by torch.distributed.run) the frame is
+split by interleaved rows across ranks (no data-path collective; rank 0 gathers the
+rendered rows), or with --split sample every rank renders all pixels for spp/N of the
+samples and the f64 accumulation images are summed with one RCCL reduce.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (extend =
+closest-hit queries) against HBM with the algorithmic bytes of DESIGN.md;
+`cpu_baseline` times the CPU oracle (a C++ restatement of the reference algorithm,
+not the reference itself: no Rust toolchain exists here) on a bounded sample of the
+same workload on the host cores of the same box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# bytes one closest-hit query moves through the ray queues in HBM: ray in (7 f64) + hit record out (t, ref)
+EXTEND_BYTES_PER_SEGMENT = 56 + 16
+# bytes per path segment over the whole extend + bin + shade step, and per sample for the accumulator
+PIPELINE_BYTES_PER_SEGMENT = 272
+PIPELINE_BYTES_PER_SAMPLE = 24
+HBM_PEAK_GBS = 8000.0
+FP64_VALU_PEAK_TOPS = 39.3  # 78.6 TFLOP/s counts an FMA as 2; this path may not fuse
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--spp", type=int, default=0, help="override the configuration's samples per pixel")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--split", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--paths-per-pass", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work to spend on the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, world, seconds):
+    """Times the CPU oracle on the same scene, camera and frame at a reduced sample count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    cam = cfg.camera()
+    threads = oracle_lib.lib().oracle_max_threads()
+    # calibrate on one whole frame at 1 spp (rows differ in cost: sky vs ground), then
+    # spend about `seconds`
+    _, _, _, per_frame_spp1 = oracle_lib.render(world.desc, cam, cfg.background, cfg.width, cfg.height, 1)
+    spp = int(max(1, min(cfg.spp, seconds / max(per_frame_spp1, 1e-3))))
+    _, _, ctr, secs = oracle_lib.render(world.desc, cam, cfg.background, cfg.width, cfg.height, spp)
+    samples = cfg.width * cfg.height * spp
+    return {
+        "value": samples / secs / 1e6,
+        "unit": "Msamples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{cfg.width}x{cfg.height} frame of the same scene and camera at {spp} spp ({samples} samples, "
+                  f"{secs:.1f} s), f64 C++ restatement of the reference algorithm, OpenMP dynamic over pixels",
+        "mrays_per_s": ctr["segments"] / secs / 1e6,
+        "box_tests_per_segment": ctr["box_tests"] / max(1, ctr["segments"]),
+        "leaf_tests_per_segment": ctr["leaf_tests"] / max(1, ctr["segments"]),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world_size
+
+    import torch
+    import torch.distributed as dist
+
+    from ray_tracer_amd import api, configs
+
+    if not torch.cuda.is_available() or api.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: no HIP device visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    gloo = None
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        gloo = dist.new_group(backend="gloo")
+
+    cfg = configs.ALL[args.config]
+    if args.spp or args.width or args.height:
+        cfg = cfg.scaled(args.width or cfg.width, args.height or cfg.height, args.spp or cfg.spp)
+    W, H, spp = cfg.width, cfg.height, cfg.spp
+    world = cfg.world()
+    cam = cfg.camera()
+    scene = api.Scene(world)  # scene resident in HBM before the timed region
+    profile = not args.no_profile
+
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    accum = torch.zeros(H * W * 3, dtype=torch.float64, device=dev) if args.split == "sample" else None
+    step_stats = []
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        if args.split == "tile" or world_size == 1:
+            # rows interleaved over ranks: tile = one row, rank r owns rows r, r + N, ...
+            _, st = api.render_world(cfg.background, scene, cam, W, H, spp, paths_per_pass=args.paths_per_pass,
+                                     profile=profile, out=out, return_stats=True, tiles=(W, world_size, rank))
+            if world_size > 1:
+                mine = torch.from_numpy(np.ascontiguousarray(out[rank::world_size]))
+                if rank == 0:
+                    parts = [torch.empty_like(torch.from_numpy(np.ascontiguousarray(out[r::world_size])))
+                             for r in range(world_size)]
+                    dist.gather(mine, parts, dst=0, group=gloo)
+                    for r in range(1, world_size):
+                        out[r::world_size] = parts[r].numpy()
+                else:
+                    dist.gather(mine, None, dst=0, group=gloo)
+        else:
+            accum.zero_()
+            lo = rank * spp // world_size
+            hi = (rank + 1) * spp // world_size
+            st = api.render_accumulate(scene, cam, cfg.background, W, H, spp, accum.data_ptr(), sample_range=(lo, hi),
+                                       paths_per_pass=args.paths_per_pass, profile=profile)
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+            if rank == 0:
+                api.resolve(accum.data_ptr(), W, H, spp, out=out)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_stats.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sums over ranks of what each rank's library calls report
+    keys = ("samples", "segments", "launches_extend", "ms_extend", "ms_shade", "ms_bin", "ms_raygen", "ms_accumulate")
+    local = torch.tensor([sum(st[k] for st in step_stats) for k in keys], dtype=torch.float64, device=dev)
+    local_max_extend = torch.tensor([sum(st["ms_extend"] for st in step_stats)], dtype=torch.float64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(local, op=dist.ReduceOp.SUM)
+        dist.all_reduce(local_max_extend, op=dist.ReduceOp.MAX)
+    tot = dict(zip(keys, local.tolist()))
+
+    if rank == 0:
+        samples = float(W) * H * spp * args.steps
+        assert abs(tot["samples"] - samples) < 0.5, (tot["samples"], samples)
+        value = samples / elapsed / 1e6
+        result = {
+            "metric": "Msamples/s (camera paths x spp per second), RTIOW final scene 1200x800" if args.config == "C2"
+                      else f"Msamples/s (camera paths x spp per second), {cfg.name}",
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (seeded scene generator, world seed 0x5EED0001, render seed 0x5EED0002)",
+            "config": {
+                "workload": cfg.name,
+                "width": W, "height": H, "spp": spp, "max_depth": api.MAX_DEPTH,
+                "shapes": world.n_shapes, "bvh_members": world.n_nodes,
+                "split": args.split if world_size > 1 else "none",
+                "traversal": "fast (near-first, distance-pruned, reference hit/miss decisions)",
+            },
+            "mrays_per_s": tot["segments"] / elapsed / 1e6,
+            "segments_per_sample": tot["segments"] / samples,
+        }
+        if profile and tot["ms_extend"] > 0:
+            launches = tot["launches_extend"]
+            avg_ms = tot["ms_extend"] / launches
+            bytes_per_launch = tot["segments"] * EXTEND_BYTES_PER_SEGMENT / launches
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            result["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_extend (closest-hit query of every live path of one bounce)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_unit": EXTEND_BYTES_PER_SEGMENT,
+                "units_per_launch": tot["segments"] / launches,
+                "avg_launch_ms": avg_ms,
+                "launches": launches,
+                "pipeline_gbs": (tot["segments"] * PIPELINE_BYTES_PER_SEGMENT + samples * PIPELINE_BYTES_PER_SAMPLE)
+                                / elapsed / 1e9,
+            }
+            result["kernel_ms"] = {k[3:]: tot[k] / world_size for k in keys if k.startswith("ms_")}
+        if args.cpu_seconds > 0 and world_size == 1:
+            base = cpu_baseline(cfg, world, args.cpu_seconds)
+            result["cpu_baseline"] = base
+            if "roofline" in result:
+                # FP64 VALU view of the same kernel: operations the reference algorithm needs for
+                # these rays (27 per box test, 33 per leaf test, counted by the oracle) per second
+                ops = tot["segments"] * (27 * base["box_tests_per_segment"] + 33 * base["leaf_tests_per_segment"])
+                result["roofline"]["valu_f64"] = {
+                    "achieved_tops": ops / (local_max_extend.item() * 1e-3) / 1e12,
+                    "peak_tops": FP64_VALU_PEAK_TOPS,
+                    "note": "reference-traversal op count of these rays / extend kernel time",
+                }
+                result["roofline"]["valu_f64"]["frac"] = result["roofline"]["valu_f64"]["achieved_tops"] / FP64_VALU_PEAK_TOPS
+        print(json.dumps(result))
+
+    scene.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -200,6 +200,12 @@ typedef struct mirt_render_opts {
     uint32_t sample_end;     /* 0 = spp */
     uint32_t paths_per_pass; /* target number of paths resident per pass; 0 = default */
     int32_t profile;         /* 1 = time each kernel class with HIP events (fills mirt_stats.ms_*) */
+    /* Tile split across devices: of the pixel range, cut into tiles of tile_size
+     * consecutive pixels, only tiles t with t % tile_count == tile_index are
+     * rendered (and written to out_rgb).  tile_count <= 1 renders the whole range. */
+    uint32_t tile_size;
+    uint32_t tile_count;
+    uint32_t tile_index;
 } mirt_render_opts;
 
 typedef struct mirt_stats {
@@ -274,6 +280,12 @@ int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera,
  * their own offsets in out_rgb. */
 int mirt_resolve(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp,
                  uint32_t pixel_begin, uint32_t pixel_end, int device, uint8_t* out_rgb);
+
+/* Same for the tile subset (tile_size, tile_count, tile_index) of the range, as in
+ * mirt_render_opts: only the selected pixels of out_rgb are written. */
+int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp,
+                       uint32_t pixel_begin, uint32_t pixel_end, uint32_t tile_size, uint32_t tile_count,
+                       uint32_t tile_index, int device, uint8_t* out_rgb);
 
 /* Camera::ray (src/camera.rs:65-88) for sample `sample` of pixel `pixel`
  * (idx of renderer.rs:74-75) for n consecutive (pixel, sample) pairs starting

@@ -111,6 +111,9 @@ class RenderOpts(C.Structure):
         ("sample_end", C.c_uint32),
         ("paths_per_pass", C.c_uint32),
         ("profile", C.c_int32),
+        ("tile_size", C.c_uint32),
+        ("tile_count", C.c_uint32),
+        ("tile_index", C.c_uint32),
     ]
 
 
@@ -188,6 +191,11 @@ MIRT_SYMBOLS = {
     "mirt_resolve": (
         C.c_int,
         [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint8)],
+    ),
+    "mirt_resolve_tiles": (
+        C.c_int,
+        [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+         C.c_int, C.POINTER(C.c_uint8)],
     ),
     "mirt_camera_rays": (
         C.c_int,

@@ -330,13 +330,17 @@ __device__ __forceinline__ HitRec bvh_closest_fast(const DScene& sc, const RayD&
     };
 
     uint32_t cur = sc.root_ref;
-    if (cur & REF_LEAF) {
+    if ((cur & REF_LEAF) && !(cur & REF_GATED)) {  // a one-shape world: the root is a bare leaf (bvh.rs:179-180)
         consider(cur);
         return best;
     }
     {
         double e;
         if (!slab_test(&sc.root_box[0][0], r, p, t_min, t_max, &e)) return best;
+    }
+    if (cur & REF_LEAF) {
+        consider(cur);
+        return best;
     }
     int sp = 0;
     for (;;) {
@@ -345,13 +349,14 @@ __device__ __forceinline__ HitRec bvh_closest_fast(const DScene& sc, const RayD&
         double e0, e1;
         bool pass0 = slab_test(&n->box[0][0][0], r, p, t_min, t_max, &e0);
         bool pass1 = slab_test(&n->box[1][0][0], r, p, t_min, t_max, &e1);
-        // A leaf child is not slab-tested by the reference: always test the shape.
+        // An ungated leaf is tested whatever its (advisory) box says; a gated one only
+        // if its box -- the exact box of the reference node it hangs from -- passed.
         if (c0 & REF_LEAF) {
-            consider(c0);
+            if (!(c0 & REF_GATED) || pass0) consider(c0);
             pass0 = false;
         }
         if (c1 & REF_LEAF) {
-            consider(c1);
+            if (!(c1 & REF_GATED) || pass1) consider(c1);
             pass1 = false;
         }
         if (have) {

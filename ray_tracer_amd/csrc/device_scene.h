@@ -10,23 +10,26 @@ namespace mirt {
 
 // A reference to a BVH child or a stack entry.
 //   bit 31      : 1 = leaf (a shape), 0 = inner node
-//   leaf        : bits 28..30 = MIRT_SHAPE_* kind, bits 0..27 = index into the sorted shape array
+//   leaf        : bit 30 = gated (test the shape only if the box stored beside this
+//                 reference passes the slab test), bits 27..29 = MIRT_SHAPE_* kind,
+//                 bits 0..26 = index into the sorted shape array
 //   inner node  : bits 0..30 = index into the DNode array
 constexpr uint32_t REF_LEAF = 0x80000000u;
-constexpr uint32_t REF_KIND_SHIFT = 28;
-constexpr uint32_t REF_INDEX_MASK = 0x0FFFFFFFu;
-constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^28 - 1
+constexpr uint32_t REF_GATED = 0x40000000u;
+constexpr uint32_t REF_KIND_SHIFT = 27;
+constexpr uint32_t REF_INDEX_MASK = 0x07FFFFFFu;
+constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^27 - 1
 
 // One inner node of the traversal tree: one 128-byte line (the L2 line size on
 // gfx950) holding the boxes of BOTH children, so that one fetch serves two slab
 // tests and the near child can be taken first.
 //
-// box[c][axis][0/1] = min/max of child c along axis.  For an inner child this
-// is the `bounds` of that BVHMember::Node (src/bvh.rs:95-99), whose slab test
-// decides hit/miss exactly as the reference does.  For a leaf child -- which
-// carries no box in the reference and is never slab-tested there -- it is the
-// shape's own bounding box, used only to order and distance-prune, never to
-// reject.
+// box[c][axis][0/1] = min/max of child c along axis.  For an inner child, or a
+// gated leaf, the slab test of this box decides whether the child is entered.
+// For an ungated leaf child -- a leaf carries no box in the reference and is never
+// slab-tested there (src/bvh.rs:45-48) -- it is the shape's own bounding box, kept
+// only to order and distance-prune, never to reject.  accel_build.h says which
+// boxes these are and why the decisions equal the reference's.
 struct alignas(128) DNode {
     double box[2][3][2];
     uint32_t child[2];

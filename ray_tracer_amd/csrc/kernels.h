@@ -30,6 +30,7 @@ constexpr int BLOCK = 256;               // threads per workgroup (4 waves)
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;
 constexpr uint32_t HIT_SIDE_SHIFT = 28;
+constexpr uint32_t HIT_PRIM_MASK = 0x0FFFFFFFu;
 
 // Per-pass path state, structure of arrays, `capacity` slots each.
 struct Paths {
@@ -57,13 +58,35 @@ struct Counters {
     __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES; }
 };
 
+// The pixels one call renders: those idx in [pixel_begin, pixel_end) whose tile
+// ((idx - pixel_begin) / tile_size) is congruent to tile_index modulo tile_count.
+// tile_count = 1 selects the whole range.  Local pixel k is the k-th such idx.
+struct PixelSet {
+    uint32_t pixel_begin;
+    uint32_t n_pixels;  // number of selected pixels
+    uint32_t tile_size, tile_count, tile_index;
+    __host__ __device__ uint32_t idx(uint32_t k) const {
+        if (tile_count <= 1) return pixel_begin + k;
+        const uint32_t t = k / tile_size;
+        return pixel_begin + (t * tile_count + tile_index) * tile_size + k % tile_size;
+    }
+    // how many pixels of a range of `len` pixels the set selects
+    static uint32_t count(uint32_t len, uint32_t tile_size, uint32_t tile_count, uint32_t tile_index) {
+        if (tile_count <= 1) return len;
+        const uint32_t full = len / tile_size, rem = len % tile_size;
+        uint32_t n = full > tile_index ? (full - tile_index + tile_count - 1) / tile_count * tile_size : 0;
+        if (rem && full % tile_count == tile_index) n += rem;
+        return n;
+    }
+};
+
 struct RenderParams {
     mirt_camera cam;
     double background[3];
     uint32_t width, height;
     uint32_t max_depth;
-    uint32_t pixel_begin;   // first pixel idx of the range
-    uint32_t n_pixels;      // pixels in the range
+    PixelSet px;            // the pixels of this call
+    uint32_t n_pixels;      // = px.n_pixels
     uint32_t sample_base;   // first sample index of this pass
     uint32_t n_samples;     // samples per pixel in this pass (B)
     uint32_t n_paths;       // n_pixels * n_samples
@@ -111,12 +134,12 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DScene sc, const mirt_ray* 
 }
 
 // ---------------------------------------------------------------------- raygen
-// Slot s holds sample (sample_base + s / n_pixels) of pixel (pixel_begin + s % n_pixels):
+// Slot s holds sample (sample_base + s / n_pixels) of the (s % n_pixels)-th pixel of the set:
 // consecutive lanes start neighbouring pixels of one sample index.
 __global__ __launch_bounds__(BLOCK) void k_raygen(Paths P, RenderParams rp) {
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < rp.n_paths; slot += stride) {
-        const uint32_t idx = rp.pixel_begin + slot % rp.n_pixels;
+        const uint32_t idx = rp.px.idx(slot % rp.n_pixels);
         const uint32_t sample = rp.sample_base + slot / rp.n_pixels;
         PathRng rng{mirt_rng_stream(rp.seed, idx, sample), 0u, 0u};
         RayD r = camera_ray(rp.cam, rp.width, rp.height, idx, rng);
@@ -307,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
                 r.time = P.time[slot];
                 const uint32_t ref = P.hit_ref[slot];
                 const Surface h =
-                    surface_at(sc, r, P.hit_t[slot], ref & REF_INDEX_MASK, (int)(ref >> HIT_SIDE_SHIFT));
+                    surface_at(sc, r, P.hit_t[slot], ref & HIT_PRIM_MASK, (int)(ref >> HIT_SIDE_SHIFT));
                 const mirt_material* __restrict__ m = sc.materials + h.material;
                 const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
                 if (cls == SHADE_LIGHT) {
@@ -381,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
 __global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, double* __restrict__ accum) {
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < rp.n_pixels; k += stride) {
-        const size_t idx = (size_t)rp.pixel_begin + k;
+        const size_t idx = rp.px.idx(k);
         double r = accum[3 * idx + 0], g = accum[3 * idx + 1], b = accum[3 * idx + 2];
         for (uint32_t s = 0; s < rp.n_samples; ++s) {
             const size_t slot = (size_t)s * rp.n_pixels + k;
@@ -410,12 +433,13 @@ __device__ __forceinline__ uint8_t f64_as_u8(double x) {
     return (uint8_t)(int)x;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_resolve(const double* __restrict__ accum, uint32_t pixel_begin,
-                                                   uint32_t n_pixels, uint32_t spp, uint8_t* __restrict__ out) {
+// out[k] = bytes of the k-th pixel of the set.
+__global__ __launch_bounds__(BLOCK) void k_resolve(const double* __restrict__ accum, PixelSet px, uint32_t spp,
+                                                   uint8_t* __restrict__ out) {
     const uint32_t stride = gridDim.x * BLOCK;
     const double n = (double)spp;
-    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n_pixels; k += stride) {
-        const size_t idx = (size_t)pixel_begin + k;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < px.n_pixels; k += stride) {
+        const size_t idx = px.idx(k);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double v = accum[3 * idx + c] / n;

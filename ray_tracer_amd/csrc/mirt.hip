@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/mirt.h"
+#include "accel_build.h"
 #include "kernels.h"
 
 using namespace mirt;
@@ -83,6 +84,7 @@ struct mirt_scene {
     uint32_t height = 0;        // levels of inner nodes on the longest root-to-leaf chain
     bool has_bvh = false;
     bool has_noise = false;
+    bool regrouped = false;     // fast tree = SAH over the reference's leaf groups (else: reference topology)
     int cu_count = 0;
 };
 
@@ -111,48 +113,6 @@ static uint32_t shade_class_of(const mirt_scene_desc* desc, const mirt_material&
         case MIRT_TEX_NOISE: return SHADE_LAMBERTIAN_NOISE;
         case MIRT_TEX_IMAGE: return SHADE_LAMBERTIAN_IMAGE;
         default: return SHADE_LAMBERTIAN_CONSTANT;
-    }
-}
-
-// Bounding box of a leaf child, stored in its parent only to order and
-// distance-prune (the reference never slab-tests a leaf).  A moving sphere is
-// boxed over its own [time_start, time_end].
-static void advisory_box(const mirt_shape& s, double lo[3], double hi[3]) {
-    auto sphere = [&](const double c[3], double r, double l[3], double h[3]) {
-        const double a = std::fabs(r);
-        for (int k = 0; k < 3; ++k) {
-            l[k] = c[k] - a;
-            h[k] = c[k] + a;
-        }
-    };
-    const double pad = 0.0001;
-    switch (s.kind) {
-        case MIRT_SHAPE_SPHERE: sphere(s.f, s.f[3], lo, hi); break;
-        case MIRT_SHAPE_MOVING_SPHERE: {
-            double l2[3], h2[3];
-            sphere(s.f, s.f[3], lo, hi);
-            sphere(s.f + 4, s.f[3], l2, h2);
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::fmin(lo[k], l2[k]);
-                hi[k] = std::fmax(hi[k], h2[k]);
-            }
-            break;
-        }
-        case MIRT_SHAPE_XY_RECT:
-            lo[0] = s.f[0]; hi[0] = s.f[1]; lo[1] = s.f[2]; hi[1] = s.f[3]; lo[2] = s.f[4] - pad; hi[2] = s.f[4] + pad;
-            break;
-        case MIRT_SHAPE_XZ_RECT:
-            lo[0] = s.f[0]; hi[0] = s.f[1]; lo[2] = s.f[2]; hi[2] = s.f[3]; lo[1] = s.f[4] - pad; hi[1] = s.f[4] + pad;
-            break;
-        case MIRT_SHAPE_YZ_RECT:
-            lo[1] = s.f[0]; hi[1] = s.f[1]; lo[2] = s.f[2]; hi[2] = s.f[3]; lo[0] = s.f[4] - pad; hi[0] = s.f[4] + pad;
-            break;
-        default:  // cube
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::fmin(s.f[k], s.f[3 + k]) - pad;
-                hi[k] = std::fmax(s.f[k], s.f[3 + k]) + pad;
-            }
-            break;
     }
 }
 
@@ -249,61 +209,27 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     }
     for (uint32_t i = 0; i < desc->n_textures; ++i) has_noise |= desc->textures[i].kind == MIRT_TEX_NOISE;
 
-    std::vector<DNode> nodes;
-    uint32_t root_ref = 0, height = 0;
+    BuiltTree tree;
     if (desc->nodes) {
-        const uint32_t nm = desc->n_nodes;
-        auto leaf_ref = [&](const mirt_bvh_member& m) {
-            return REF_LEAF | (desc->shapes[m.shape].kind << REF_KIND_SHIFT) | m.shape;
-        };
-        const mirt_bvh_member& root = desc->nodes[nm - 1];
-        if (root.is_leaf) {
-            root_ref = leaf_ref(root);
-        } else {
-            // breadth-first numbering from the root: the levels every ray visits sit together
-            std::vector<uint32_t> order;  // member index of node k
-            std::vector<uint32_t> node_of(nm, 0xFFFFFFFFu), level(nm, 0);
-            order.push_back(nm - 1);
-            node_of[nm - 1] = 0;
-            level[nm - 1] = 1;
-            for (size_t k = 0; k < order.size(); ++k) {
-                const mirt_bvh_member& m = desc->nodes[order[k]];
-                height = std::max(height, level[order[k]]);
-                for (uint32_t child : {m.left, m.right})
-                    if (!desc->nodes[child].is_leaf) {
-                        node_of[child] = (uint32_t)order.size();
-                        level[child] = level[order[k]] + 1;
-                        order.push_back(child);
-                    }
-            }
-            nodes.resize(order.size());
-            for (size_t k = 0; k < order.size(); ++k) {
-                const mirt_bvh_member& m = desc->nodes[order[k]];
-                DNode& n = nodes[k];
-                std::memset(&n, 0, sizeof n);
-                const uint32_t kids[2] = {m.left, m.right};
-                for (int c = 0; c < 2; ++c) {
-                    const mirt_bvh_member& ch = desc->nodes[kids[c]];
-                    double lo[3], hi[3];
-                    if (ch.is_leaf) {
-                        n.child[c] = leaf_ref(ch);
-                        advisory_box(desc->shapes[ch.shape], lo, hi);
-                    } else {
-                        n.child[c] = node_of[kids[c]];
-                        std::memcpy(lo, ch.bmin, sizeof lo);
-                        std::memcpy(hi, ch.bmax, sizeof hi);
-                    }
-                    for (int a = 0; a < 3; ++a) {
-                        n.box[c][a][0] = lo[a];
-                        n.box[c][a][1] = hi[a];
-                    }
-                }
-            }
-            root_ref = 0;
+        // The regrouped tree needs every Node box to contain its inner children's boxes
+        // (true of any tree BoundingVolumeHierarchy::new builds); otherwise keep the
+        // reference's own topology.
+        tree = boxes_nest(desc) ? regroup(desc, MAX_TREE_HEIGHT) : flatten_reference(desc);
+        if (tree.height > (uint32_t)MAX_TREE_HEIGHT)
+            return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", tree.height, MAX_TREE_HEIGHT);
+        // the reference-order kernel walks the caller's own members: bound their depth too
+        std::vector<uint32_t> level(desc->n_nodes, 1);
+        uint32_t deepest = 1;
+        for (uint32_t i = desc->n_nodes; i-- > 0;) {
+            const mirt_bvh_member& m = desc->nodes[i];
+            deepest = std::max(deepest, level[i]);
+            if (!m.is_leaf) level[m.left] = level[m.right] = level[i] + 1;
         }
-        if (height + 1 > (uint32_t)MAX_TREE_HEIGHT)
-            return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", height + 1, MAX_TREE_HEIGHT);
+        if (deepest > (uint32_t)MAX_TREE_HEIGHT)
+            return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", deepest, MAX_TREE_HEIGHT);
     }
+    const std::vector<DNode>& nodes = tree.nodes;
+    const uint32_t root_ref = tree.root_ref, height = tree.height;
 
     // ---- upload
     auto* sc = new (std::nothrow) mirt_scene();
@@ -369,13 +295,8 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     sc->d.n_members = desc->nodes ? desc->n_nodes : 0;
     sc->d.n_nodes = (uint32_t)nodes.size();
     sc->d.root_ref = root_ref;
-    if (desc->nodes && !desc->nodes[desc->n_nodes - 1].is_leaf) {
-        const mirt_bvh_member& root = desc->nodes[desc->n_nodes - 1];
-        for (int a = 0; a < 3; ++a) {
-            sc->d.root_box[a][0] = root.bmin[a];
-            sc->d.root_box[a][1] = root.bmax[a];
-        }
-    }
+    std::memcpy(sc->d.root_box, tree.root_box, sizeof tree.root_box);
+    sc->regrouped = tree.regrouped;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) sc->cu_count = prop.multiProcessorCount;
     if (sc->cu_count <= 0) sc->cu_count = 256;
@@ -562,7 +483,19 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     if ((rc = guard.enter(scene->device)) != MIRT_OK) return rc;
 
     const auto t_start = std::chrono::steady_clock::now();
-    const uint32_t n_pixels = o.pixel_end - o.pixel_begin;
+    if (o.tile_count > 1 && (o.tile_size == 0 || o.tile_index >= o.tile_count))
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "bad tile split: size %u, count %u, index %u", o.tile_size, o.tile_count, o.tile_index);
+    PixelSet px;
+    px.pixel_begin = o.pixel_begin;
+    px.tile_size = o.tile_size;
+    px.tile_count = o.tile_count;
+    px.tile_index = o.tile_index;
+    px.n_pixels = PixelSet::count(o.pixel_end - o.pixel_begin, o.tile_size, o.tile_count, o.tile_index);
+    const uint32_t n_pixels = px.n_pixels;
+    if (n_pixels == 0) {  // this tile index owns nothing of the range
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return MIRT_OK;
+    }
     const uint32_t n_samples_total = o.sample_end - o.sample_begin;
     const uint64_t target = o.paths_per_pass ? o.paths_per_pass : (1ull << 23);
     uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, target / n_pixels));
@@ -596,7 +529,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     rp.width = width;
     rp.height = height;
     rp.max_depth = max_depth;
-    rp.pixel_begin = o.pixel_begin;
+    rp.px = px;
     rp.n_pixels = n_pixels;
     rp.seed = seed;
     rp.t_min = 0.001;
@@ -689,25 +622,48 @@ int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera, c
     return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats);
 }
 
-int mirt_resolve(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
-                 uint32_t pixel_end, int device, uint8_t* out_rgb) {
+int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
+                       uint32_t pixel_end, uint32_t tile_size, uint32_t tile_count, uint32_t tile_index, int device,
+                       uint8_t* out_rgb) {
     if (!d_accum || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
     if (width == 0 || height == 0 || spp == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image or spp = 0");
     if (pixel_end == 0) pixel_end = width * height;
     if (pixel_begin >= pixel_end || pixel_end > width * height) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad pixel range");
+    if (tile_count > 1 && (tile_size == 0 || tile_index >= tile_count)) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad tile split");
     if (mirt_device_count() == 0) return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible");
     DeviceGuard guard;
     int rc = guard.enter(device);
     if (rc != MIRT_OK) return rc;
-    const uint32_t n = pixel_end - pixel_begin;
+    PixelSet px;
+    px.pixel_begin = pixel_begin;
+    px.tile_size = tile_size;
+    px.tile_count = tile_count;
+    px.tile_index = tile_index;
+    px.n_pixels = PixelSet::count(pixel_end - pixel_begin, tile_size, tile_count, tile_index);
+    const uint32_t n = px.n_pixels;
+    if (n == 0) return MIRT_OK;
     DeviceArena arena;
     uint8_t* d_out = nullptr;
     HIP_TRY(arena.alloc(&d_out, (size_t)n * 3));
     const int grid = (int)std::min<size_t>(((size_t)n + BLOCK - 1) / BLOCK, 4096);
-    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, 0, d_accum, pixel_begin, n, spp, d_out);
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, 0, d_accum, px, spp, d_out);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out_rgb + (size_t)pixel_begin * 3, d_out, (size_t)n * 3, hipMemcpyDeviceToHost));
+    if (tile_count <= 1) {
+        HIP_TRY(hipMemcpy(out_rgb + (size_t)pixel_begin * 3, d_out, (size_t)n * 3, hipMemcpyDeviceToHost));
+        return MIRT_OK;
+    }
+    std::vector<uint8_t> compact((size_t)n * 3);
+    HIP_TRY(hipMemcpy(compact.data(), d_out, compact.size(), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < n; k += tile_size) {  // one run of consecutive pixels per tile
+        const uint32_t run = std::min(tile_size, n - k);
+        std::memcpy(out_rgb + (size_t)px.idx(k) * 3, compact.data() + (size_t)k * 3, (size_t)run * 3);
+    }
     return MIRT_OK;
+}
+
+int mirt_resolve(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
+                 uint32_t pixel_end, int device, uint8_t* out_rgb) {
+    return mirt_resolve_tiles(d_accum, width, height, spp, pixel_begin, pixel_end, 0, 1, 0, device, out_rgb);
 }
 
 int mirt_render(const mirt_scene* scene, const mirt_camera* camera, const double background[3], uint32_t width,
@@ -736,7 +692,8 @@ int mirt_render(const mirt_scene* scene, const mirt_camera* camera, const double
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, 0));
     }
-    rc = mirt_resolve(d_accum, width, height, spp, pb, pe, scene->device, out_rgb);
+    rc = mirt_resolve_tiles(d_accum, width, height, spp, pb, pe, opts ? opts->tile_size : 0, opts ? opts->tile_count : 1,
+                            opts ? opts->tile_index : 0, scene->device, out_rgb);
     if (prof) {
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);

@@ -61,3 +61,42 @@ def test_linear_list_render_matches_oracle(worlds, oracle):
     gpu_rgb, stats = api.render_world(cfg.background, world, cam, w, h, spp, use_bounding_volume=False, return_stats=True)
     assert stats["segments"] == ctr["segments"]
     assert np.abs(gpu_rgb.astype(int) - ref_rgb.astype(int)).max() <= 1
+
+
+def test_tile_split_and_sample_split_reassemble_the_image(worlds):
+    """What N ranks would each render, done one after the other on one device: interleaved
+    row tiles reassemble to the single-device image bit for bit; sample ranges summed in
+    f64 give the same bytes."""
+    import torch
+
+    cfg = configs.C1
+    w, h, spp = 64, 36, 8
+    world = worlds("C1")
+    cam = cfg.camera(w, h)
+    scene = api.Scene(world)
+    try:
+        full = api.render_world(cfg.background, scene, cam, w, h, spp)
+        for n_ranks in (2, 3, 8):
+            tiled = np.zeros_like(full)
+            for r in range(n_ranks):
+                api.render_world(cfg.background, scene, cam, w, h, spp, out=tiled, tiles=(w, n_ranks, r))
+            assert np.array_equal(full, tiled), n_ranks
+        # odd tile size with a ragged last tile
+        tiled = np.zeros_like(full)
+        for r in range(4):
+            api.render_world(cfg.background, scene, cam, w, h, spp, out=tiled, tiles=(100, 4, r))
+        assert np.array_equal(full, tiled)
+        for n_ranks in (2, 4):
+            total = torch.zeros(w * h * 3, dtype=torch.float64, device="cuda")
+            for r in range(n_ranks):
+                part = torch.zeros_like(total)
+                api.render_accumulate(scene, cam, cfg.background, w, h, spp, part.data_ptr(),
+                                      sample_range=(r * spp // n_ranks, (r + 1) * spp // n_ranks))
+                total += part
+            torch.cuda.synchronize()
+            summed = api.resolve(total.data_ptr(), w, h, spp)
+            # f64 sums in a different order: a byte may move by one level at most
+            assert np.abs(summed.astype(int) - full.astype(int)).max() <= 1
+            assert np.count_nonzero(summed != full) <= 2
+    finally:
+        scene.close()
