@@ -221,12 +221,19 @@ struct Builder {
         Box box;
     };
 
-    // A group becomes either a gated leaf (one shape: the parent's copy of the group
-    // box admits it) or a DNode whose two children are ungated leaves (the parent's
-    // copy of the group box admitted the node; nothing more gates the shapes).
+    // A group becomes a gated leaf reference -- the parent's copy of the group box admits
+    // it -- for one shape, or for two shapes with consecutive indices (what bvh.rs:187-188
+    // always produces).  Two shapes that are not neighbours get a DNode whose children
+    // are ungated leaves: the parent's copy of the group box admitted the node, nothing
+    // more gates the shapes.
     Sub emit_group(const Group& g, uint32_t depth) {
         height_seen = std::max(height_seen, depth + 1);
         if (g.n_shapes == 1) return Sub{leaf_ref(desc, g.shapes[0], true), g.box};
+        if (g.shapes[1] == g.shapes[0] + 1) {
+            const uint32_t ref = leaf_ref(desc, g.shapes[0], true) | REF_PAIR |
+                                 (desc->shapes[g.shapes[1]].kind << REF_KIND2_SHIFT);
+            return Sub{ref, g.box};
+        }
         DNode n;
         std::memset(&n, 0, sizeof n);
         for (int c = 0; c < 2; ++c) {

@@ -286,100 +286,11 @@ __device__ inline HitRec bvh_closest_reference(const DScene& sc, const RayD& r, 
     return result;
 }
 
-// ---- BVH, fast order -------------------------------------------------------------
-// Safety margin of the distance prune: a subtree is skipped only if the slab
-// entry distance of its box exceeds best_t * (1 + PRUNE_REL) + PRUNE_ABS ... see
-// bvh_closest_fast.
+// Safety margin of the distance prune of the fast traversal (device_traverse.h): a
+// child is skipped only if the slab entry distance of its box exceeds
+// best_t * (1 + PRUNE_REL).  Rounding moves either quantity by parts in 1e-16 to,
+// for a grazing hit on a very large sphere, parts in 1e-9; 1e-6 dwarfs both and
+// costs no measurable pruning.
 constexpr double PRUNE_REL = 1.0e-6;
-
-// Walks the two-boxes-per-node tree with a per-lane stack in LDS (`stack`,
-// laid out [level][thread] so that a wave's 64 entries of one level are 64
-// consecutive dwords: conflict-free).
-//
-// Same answer as bvh_closest_reference whenever no primitive reports a NaN t:
-//  * an inner child is entered iff its box passes the reference slab test with
-//    the caller's (t_min, t_max) -- never a tightened t_max;
-//  * every leaf so reached is tested with the caller's (t_min, t_max);
-//  * the winner is the smallest t, and among equal t the largest shape index,
-//    which is what "left only if left.t < right.t" yields over leaves ordered
-//    left to right (leaf order = shape index order);
-//  * additionally a child is skipped when its box is entered farther than the
-//    best t so far by a relative margin that dwarfs the rounding of either
-//    quantity; such a child cannot hold a hit with t <= best_t.
-template <int BLOCK>
-__device__ __forceinline__ HitRec bvh_closest_fast(const DScene& sc, const RayD& r, double t_min, double t_max,
-                                                   uint32_t* __restrict__ stack, int tid) {
-    HitRec best{0.0, -1, 0};
-    const RayPre p = ray_pre(r);
-    double best_t = t_max;       // only used for pruning until a hit exists
-    bool have = false;
-
-    auto consider = [&](uint32_t ref) {
-        const uint32_t kind = (ref >> REF_KIND_SHIFT) & 7u;
-        const uint32_t index = ref & REF_INDEX_MASK;
-        double t;
-        int side;
-        if (shape_hit(sc.shapes, index, kind, r, p.dd, t_min, t_max, &t, &side)) {
-            // smallest t wins; equal t: larger index wins (bvh.rs:70-74)
-            if (!have || t < best.t || (t == best.t && (int32_t)index > best.prim)) {
-                best = HitRec{t, (int32_t)index, side};
-                best_t = t;
-                have = true;
-            }
-        }
-    };
-
-    uint32_t cur = sc.root_ref;
-    if ((cur & REF_LEAF) && !(cur & REF_GATED)) {  // a one-shape world: the root is a bare leaf (bvh.rs:179-180)
-        consider(cur);
-        return best;
-    }
-    {
-        double e;
-        if (!slab_test(&sc.root_box[0][0], r, p, t_min, t_max, &e)) return best;
-    }
-    if (cur & REF_LEAF) {
-        consider(cur);
-        return best;
-    }
-    int sp = 0;
-    for (;;) {
-        const DNode* __restrict__ n = sc.nodes + cur;
-        const uint32_t c0 = n->child[0], c1 = n->child[1];
-        double e0, e1;
-        bool pass0 = slab_test(&n->box[0][0][0], r, p, t_min, t_max, &e0);
-        bool pass1 = slab_test(&n->box[1][0][0], r, p, t_min, t_max, &e1);
-        // An ungated leaf is tested whatever its (advisory) box says; a gated one only
-        // if its box -- the exact box of the reference node it hangs from -- passed.
-        if (c0 & REF_LEAF) {
-            if (!(c0 & REF_GATED) || pass0) consider(c0);
-            pass0 = false;
-        }
-        if (c1 & REF_LEAF) {
-            if (!(c1 & REF_GATED) || pass1) consider(c1);
-            pass1 = false;
-        }
-        if (have) {
-            const double limit = best_t + fabs(best_t) * PRUNE_REL;
-            if (e0 > limit) pass0 = false;
-            if (e1 > limit) pass1 = false;
-        }
-        if (pass0 && pass1) {
-            const bool near0 = e0 <= e1;
-            stack[sp * BLOCK + tid] = near0 ? c1 : c0;
-            ++sp;
-            cur = near0 ? c0 : c1;
-        } else if (pass0) {
-            cur = c0;
-        } else if (pass1) {
-            cur = c1;
-        } else {
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * BLOCK + tid];
-        }
-    }
-    return best;
-}
 
 }  // namespace mirt

@@ -9,16 +9,21 @@
 namespace mirt {
 
 // A reference to a BVH child or a stack entry.
-//   bit 31      : 1 = leaf (a shape), 0 = inner node
-//   leaf        : bit 30 = gated (test the shape only if the box stored beside this
-//                 reference passes the slab test), bits 27..29 = MIRT_SHAPE_* kind,
-//                 bits 0..26 = index into the sorted shape array
+//   bit 31      : 1 = leaf (shapes), 0 = inner node
 //   inner node  : bits 0..30 = index into the DNode array
+//   leaf        : bit 30 = gated: test the shapes only if the box stored beside this
+//                 reference passes the slab test
+//                 bit 29 = pair: two shapes, index and index + 1
+//                 bits 26..28 = MIRT_SHAPE_* kind of shape `index`
+//                 bits 23..25 = kind of shape `index + 1` (pair only)
+//                 bits 0..22  = index into the sorted shape array
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_GATED = 0x40000000u;
-constexpr uint32_t REF_KIND_SHIFT = 27;
-constexpr uint32_t REF_INDEX_MASK = 0x07FFFFFFu;
-constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^27 - 1
+constexpr uint32_t REF_PAIR = 0x20000000u;
+constexpr uint32_t REF_KIND_SHIFT = 26;
+constexpr uint32_t REF_KIND2_SHIFT = 23;
+constexpr uint32_t REF_INDEX_MASK = 0x007FFFFFu;
+constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^23 - 1
 
 // One inner node of the traversal tree: one 128-byte line (the L2 line size on
 // gfx950) holding the boxes of BOTH children, so that one fetch serves two slab

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_shade.h"
+#include "device_traverse.h"
 
 namespace mirt {
 
@@ -55,7 +56,9 @@ struct Counters {
     uint32_t depth;
     __host__ __device__ uint32_t live(uint32_t b) const { return b; }
     __host__ __device__ uint32_t cls(uint32_t b, uint32_t c) const { return depth + 1 + b * SHADE_NUM_CLASSES + c; }
-    __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES; }
+    // [D+1+8D .. D+1+9D)        work[b]     next unclaimed live entry of bounce b (fast extend kernel)
+    __host__ __device__ uint32_t work(uint32_t b) const { return depth + 1 + depth * SHADE_NUM_CLASSES + b; }
+    __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES + depth; }
 };
 
 // The pixels one call renders: those idx in [pixel_begin, pixel_end) whose tile
@@ -97,34 +100,30 @@ struct RenderParams {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ uint32_t mbcnt_lt(unsigned long long mask) {
-    // number of set bits of `mask` below this lane
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 // ---------------------------------------------------------------- closest hit
+// MODE_LIST and MODE_REFERENCE: one ray per lane from start to finish (simple forms,
+// kept for the linear-list mode of the reference and for checking the fast one).
+// MODE_FAST: the persistent traversal of device_traverse.h.
 enum : int { MODE_LIST = 0, MODE_REFERENCE = 1, MODE_FAST = 2 };
 
 template <int MODE>
-__device__ __forceinline__ HitRec closest_hit(const DScene& sc, const RayD& r, double t_min, double t_max,
-                                              uint32_t* stack, int tid) {
+__device__ __forceinline__ HitRec closest_hit(const DScene& sc, const RayD& r, double t_min, double t_max) {
     if (MODE == MODE_LIST) return list_closest(sc, r, t_min, t_max);
-    if (MODE == MODE_REFERENCE) return bvh_closest_reference(sc, r, t_min, t_max);
-    return bvh_closest_fast<BLOCK>(sc, r, t_min, t_max, stack, tid);
+    return bvh_closest_reference(sc, r, t_min, t_max);
 }
 
 // Hittable::hit for caller-supplied rays (array of structs, as the C ABI hands them over).
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_intersect(DScene sc, const mirt_ray* __restrict__ rays, size_t n,
                                                      double t_min, double t_max, mirt_hit* __restrict__ hits) {
-    __shared__ uint32_t stack[MODE == MODE_FAST ? MAX_TREE_HEIGHT * BLOCK : 1];
     const size_t stride = (size_t)gridDim.x * BLOCK;
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         RayD r;
         r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
         r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         r.time = rays[i].time;
-        HitRec h = closest_hit<MODE>(sc, r, t_min, t_max, stack, threadIdx.x);
+        HitRec h = closest_hit<MODE>(sc, r, t_min, t_max);
         mirt_hit out;
         out.prim = h.prim;
         out.side = h.prim >= 0 ? h.side : 0;
@@ -132,6 +131,60 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DScene sc, const mirt_ray* 
         hits[i] = out;
     }
 }
+
+// ---- the fast traversal as a kernel ------------------------------------------------
+constexpr int TRAV_BLOCK = 512;  // 8 waves share one LDS copy of the tree
+
+// Dynamic LDS: [stack: levels x TRAV_BLOCK entries of StackT][nodes: n_nodes x 104 B].
+__host__ __device__ inline size_t trav_stack_bytes(uint32_t levels, size_t entry) {
+    return (((size_t)levels * TRAV_BLOCK * entry) + 15) & ~(size_t)15;
+}
+
+template <class StackT, bool NODES_IN_LDS, class Io>
+__global__ __launch_bounds__(TRAV_BLOCK) void k_traverse(DScene sc, Io io, uint32_t* __restrict__ work_counter,
+                                                          double t_min, double t_max, uint32_t stack_levels) {
+    extern __shared__ __align__(16) char smem[];
+    const uint32_t n = io.count();
+    // waves beyond the number of chunks can never get work: leave before staging anything
+    const uint32_t chunk = chunk_rays(n, gridDim.x * (TRAV_BLOCK / 64));
+    const uint32_t chunks = (n + chunk - 1) / chunk;
+    if (blockIdx.x * (TRAV_BLOCK / 64) >= chunks) return;
+    StackT* stack = reinterpret_cast<StackT*>(smem);
+    char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT));
+    if (NODES_IN_LDS) {
+        // copy the first 26 dwords (boxes + child references) of every 32-dword DNode
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.nodes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
+        const uint32_t words = sc.n_nodes * (NODE_LDS_BYTES / 4);
+        for (uint32_t w = threadIdx.x; w < words; w += TRAV_BLOCK) {
+            const uint32_t node = w / (NODE_LDS_BYTES / 4), j = w % (NODE_LDS_BYTES / 4);
+            dst[w] = src[node * (sizeof(DNode) / 4) + j];
+        }
+        __syncthreads();
+    }
+    traverse_persistent<TRAV_BLOCK, StackT, NODES_IN_LDS>(sc, io, work_counter, t_min, t_max, lds_nodes, stack);
+}
+
+// Rays and hits as arrays of structs (the parity entry point).
+struct IntersectIo {
+    const mirt_ray* __restrict__ rays;
+    mirt_hit* __restrict__ hits;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t count() const { return n; }
+    __device__ __forceinline__ void load(uint32_t i, RayD* r, uint32_t* cookie) const {
+        r->o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        r->d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
+        r->time = rays[i].time;
+        *cookie = i;
+    }
+    __device__ __forceinline__ void store(uint32_t i, uint32_t, const HitRec& h) const {
+        mirt_hit out;
+        out.prim = h.prim;
+        out.side = h.prim >= 0 ? h.side : 0;
+        out.t = h.prim >= 0 ? h.t : 0.0;
+        hits[i] = out;
+    }
+};
 
 // ---------------------------------------------------------------------- raygen
 // Slot s holds sample (sample_base + s / n_pixels) of the (s % n_pixels)-th pixel of the set:
@@ -173,7 +226,6 @@ __global__ __launch_bounds__(BLOCK) void k_camera_rays(mirt_camera cam, uint32_t
 // handled by thread i mod (grid size): no atomics, no barriers.
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, Paths P, RenderParams rp, uint32_t bounce) {
-    __shared__ uint32_t stack[MODE == MODE_FAST ? MAX_TREE_HEIGHT * BLOCK : 1];
     const Counters C{rp.max_depth};
     const uint32_t n = bounce == 0 ? rp.n_paths : P.counters[C.live(bounce)];
     const uint32_t* __restrict__ qin = P.live[bounce & 1];
@@ -184,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, Paths P, RenderPara
         r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
         r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
         r.time = P.time[slot];
-        HitRec h = closest_hit<MODE>(sc, r, rp.t_min, rp.t_max, stack, threadIdx.x);
+        HitRec h = closest_hit<MODE>(sc, r, rp.t_min, rp.t_max);
         uint32_t cls = SHADE_MISS;
         uint32_t ref = HIT_MISS;
         if (h.prim >= 0) {
@@ -196,6 +248,36 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, Paths P, RenderPara
         P.cls_q[i] = (uint8_t)cls;
     }
 }
+
+// The live queue of one bounce as the ray source of the persistent traversal
+// (k_traverse<.., ExtendIo>): the extend kernel of the fast mode.
+struct ExtendIo {
+    Paths P;
+    const DShape* __restrict__ shapes;
+    const uint32_t* __restrict__ qin;  // live queue of this bounce (unused at bounce 0: entry i = slot i)
+    const uint32_t* __restrict__ n_live;  // its length in device memory (null at bounce 0)
+    uint32_t n_paths;
+    uint32_t first_bounce;
+    __device__ __forceinline__ uint32_t count() const { return first_bounce ? n_paths : *n_live; }
+    __device__ __forceinline__ void load(uint32_t i, RayD* r, uint32_t* cookie) const {
+        const uint32_t slot = first_bounce ? i : qin[i];
+        r->o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
+        r->d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
+        r->time = P.time[slot];
+        *cookie = slot;
+    }
+    __device__ __forceinline__ void store(uint32_t i, uint32_t slot, const HitRec& h) const {
+        uint32_t cls = SHADE_MISS;
+        uint32_t ref = HIT_MISS;
+        if (h.prim >= 0) {
+            cls = shapes[h.prim].cls;
+            ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
+            P.hit_t[slot] = h.t;
+        }
+        P.hit_ref[slot] = ref;
+        P.cls_q[i] = (uint8_t)cls;
+    }
+};
 
 // ------------------------------------------------------------------------- bin
 // Sorts the live queue of this bounce by shade class: a block takes a tile of

@@ -335,6 +335,73 @@ static int grid_for(const mirt_scene* scene, size_t work_items, int blocks_per_c
     return (int)std::max<size_t>(1, std::min(want, cap));
 }
 
+}  // extern "C"
+
+namespace {
+
+// How the fast traversal kernel is launched for one scene: stack entry width, whether
+// the tree is staged in LDS, dynamic LDS bytes and the persistent grid.
+struct TraversePlan {
+    bool stack16 = true;
+    bool nodes_in_lds = false;
+    size_t lds_bytes = 0;
+    uint32_t levels = 1;
+};
+
+// A block may use this much LDS and still leave room for a second block on the CU (160 KB).
+constexpr size_t TRAV_LDS_BUDGET = 78 * 1024;
+
+TraversePlan plan_traverse(const mirt_scene* scene) {
+    TraversePlan p;
+    p.levels = std::max<uint32_t>(scene->height, 1);
+    p.stack16 = scene->d.n_nodes < 65536u;
+    const size_t stack = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4);
+    const size_t nodes = (size_t)scene->d.n_nodes * NODE_LDS_BYTES;
+    p.nodes_in_lds = scene->d.n_nodes > 0 && stack + nodes <= TRAV_LDS_BUDGET;
+    p.lds_bytes = stack + (p.nodes_in_lds ? nodes : 0);
+    return p;
+}
+
+template <class StackT, bool LDS, class Io>
+hipError_t launch_traverse_as(const mirt_scene* scene, const TraversePlan& plan, const Io& io, uint32_t* work_counter,
+                              double t_min, double t_max, hipStream_t stream) {
+    auto kernel = k_traverse<StackT, LDS, Io>;
+    // grid = every block the device can hold at once (persistent waves pull work themselves)
+    static thread_local const void* sized_for = nullptr;
+    static thread_local size_t sized_bytes = 0;
+    static thread_local int per_cu = 1;
+    if (sized_for != (const void*)kernel || sized_bytes != plan.lds_bytes) {
+        if (plan.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, TRAV_BLOCK, plan.lds_bytes) != hipSuccess || n <= 0) n = 1;
+        per_cu = std::min(n, 4);
+        sized_for = (const void*)kernel;
+        sized_bytes = plan.lds_bytes;
+    }
+    const int grid = scene->cu_count * per_cu;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRAV_BLOCK), plan.lds_bytes, stream, scene->d, io, work_counter, t_min, t_max, plan.levels);
+    return hipGetLastError();
+}
+
+template <class Io>
+hipError_t launch_traverse(const mirt_scene* scene, const Io& io, uint32_t* work_counter, double t_min, double t_max,
+                           hipStream_t stream) {
+    const TraversePlan plan = plan_traverse(scene);
+    if (plan.stack16) {
+        if (plan.nodes_in_lds) return launch_traverse_as<uint16_t, true>(scene, plan, io, work_counter, t_min, t_max, stream);
+        return launch_traverse_as<uint16_t, false>(scene, plan, io, work_counter, t_min, t_max, stream);
+    }
+    if (plan.nodes_in_lds) return launch_traverse_as<uint32_t, true>(scene, plan, io, work_counter, t_min, t_max, stream);
+    return launch_traverse_as<uint32_t, false>(scene, plan, io, work_counter, t_min, t_max, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
 int mirt_intersect_device(const mirt_scene* scene, const mirt_ray* d_rays, size_t n, double t_min, double t_max,
                           int use_bvh, int traversal, mirt_hit* d_hits) {
     if (!scene) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene is null");
@@ -345,10 +412,19 @@ int mirt_intersect_device(const mirt_scene* scene, const mirt_ray* d_rays, size_
     DeviceGuard guard;
     if ((rc = guard.enter(scene->device)) != MIRT_OK) return rc;
     const int grid = grid_for(scene, n, 8);
+    DeviceArena arena;
     switch (mode) {
         case MODE_LIST: hipLaunchKernelGGL(k_intersect<MODE_LIST>, dim3(grid), dim3(BLOCK), 0, 0, scene->d, d_rays, n, t_min, t_max, d_hits); break;
         case MODE_REFERENCE: hipLaunchKernelGGL(k_intersect<MODE_REFERENCE>, dim3(grid), dim3(BLOCK), 0, 0, scene->d, d_rays, n, t_min, t_max, d_hits); break;
-        default: hipLaunchKernelGGL(k_intersect<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, 0, scene->d, d_rays, n, t_min, t_max, d_hits); break;
+        default: {
+            if (n > 0xFFFFFFFFull - CHUNK_RAYS * 4096ull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^32 rays in one call");
+            uint32_t* d_work = nullptr;
+            HIP_TRY(arena.alloc(&d_work, (size_t)1));
+            HIP_TRY(hipMemsetAsync(d_work, 0, sizeof(uint32_t), 0));
+            IntersectIo io{d_rays, d_hits, (uint32_t)n};
+            HIP_TRY(launch_traverse(scene, io, d_work, t_min, t_max, 0));
+            break;
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(0));
@@ -541,7 +617,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     switch (mode) {
         case MODE_LIST: occ_extend = blocks_per_cu(k_extend<MODE_LIST>, 4); break;
         case MODE_REFERENCE: occ_extend = blocks_per_cu(k_extend<MODE_REFERENCE>, 2); break;
-        default: occ_extend = blocks_per_cu(k_extend<MODE_FAST>, 4); break;
+        default: break;  // the fast kernel sizes its own persistent grid (launch_traverse)
     }
     const int occ_shade = scene->has_noise ? blocks_per_cu(k_shade<true>, 2) : blocks_per_cu(k_shade<false>, 4);
 
@@ -567,7 +643,11 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
             switch (mode) {
                 case MODE_LIST: hipLaunchKernelGGL(k_extend<MODE_LIST>, dim3(grid_extend), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce); break;
                 case MODE_REFERENCE: hipLaunchKernelGGL(k_extend<MODE_REFERENCE>, dim3(grid_extend), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce); break;
-                default: hipLaunchKernelGGL(k_extend<MODE_FAST>, dim3(grid_extend), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce); break;
+                default: {
+                    ExtendIo io{P, scene->d.shapes, P.live[bounce & 1], P.counters + C.live(bounce), rp.n_paths, bounce == 0 ? 1u : 0u};
+                    HIP_TRY(launch_traverse(scene, io, P.counters + C.work(bounce), rp.t_min, rp.t_max, stream));
+                    break;
+                }
             }
             HIP_TRY(timer.end(stream));
             HIP_TRY(timer.begin(stream, EventTimer::BIN));

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_extend", "k_shade", "k_bin", "k_raygen", "k_accumulate", "k_resolve", "k_intersect"):
+    for k in ("k_traverse", "k_extend", "k_shade", "k_bin", "k_raygen", "k_accumulate", "k_resolve", "k_intersect"):
         if k in name:
             return k
     return name[:40]
