@@ -163,7 +163,8 @@ def main():
         elapsed = float(t.item())
 
     # sums over ranks of what each rank's library calls report
-    keys = ("samples", "segments", "launches_extend", "ms_extend", "ms_shade", "ms_bin", "ms_raygen", "ms_accumulate")
+    keys = ("samples", "segments", "segments_tail", "launches_extend", "launches_tail", "ms_extend", "ms_shade", "ms_bin",
+            "ms_raygen", "ms_accumulate", "ms_tail")
     local = torch.tensor([sum(st[k] for st in step_stats) for k in keys], dtype=torch.float64, device=dev)
     local_max_extend = torch.tensor([sum(st["ms_extend"] for st in step_stats)], dtype=torch.float64, device=dev)
     if world_size > 1:
@@ -196,13 +197,15 @@ def main():
                 "split": args.split if world_size > 1 else "none",
                 "traversal": "fast (near-first, distance-pruned, reference hit/miss decisions)",
             },
+            "tail": {"bounce": int(step_stats[-1]["tail_bounce"]), "segments_frac": tot["segments_tail"] / max(1.0, tot["segments"])},
             "mrays_per_s": tot["segments"] / elapsed / 1e6,
             "segments_per_sample": tot["segments"] / samples,
         }
         if profile and tot["ms_extend"] > 0:
             launches = tot["launches_extend"]
             avg_ms = tot["ms_extend"] / launches
-            bytes_per_launch = tot["segments"] * EXTEND_BYTES_PER_SEGMENT / launches
+            extend_segments = tot["segments"] - tot["segments_tail"]  # the tail kernel's are not this kernel's
+            bytes_per_launch = extend_segments * EXTEND_BYTES_PER_SEGMENT / launches
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             result["roofline"] = {
                 "bound": "hbm",
@@ -213,7 +216,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "bytes_per_unit": EXTEND_BYTES_PER_SEGMENT,
-                "units_per_launch": tot["segments"] / launches,
+                "units_per_launch": extend_segments / launches,
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
                 "pipeline_gbs": (tot["segments"] * PIPELINE_BYTES_PER_SEGMENT + samples * PIPELINE_BYTES_PER_SAMPLE)

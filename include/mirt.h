@@ -206,6 +206,13 @@ typedef struct mirt_render_opts {
     uint32_t tile_size;
     uint32_t tile_count;
     uint32_t tile_index;
+    /* Scheduling only, never results: from bounce `tail_bounce` on, the paths still alive are
+     * followed to their end by one kernel instead of three launches per bounce (few paths
+     * live that long, and a launch costs more than their work).  0 = automatic: the first
+     * bounce that at most `tail_paths` paths reach (measured during the first pass of the
+     * call); N > 0 = bounce N; < 0 = never.  Fast traversal only. */
+    int32_t tail_bounce;
+    uint32_t tail_paths;     /* threshold of the automatic choice; 0 = default (half the paths of a pass) */
 } mirt_render_opts;
 
 typedef struct mirt_stats {
@@ -221,6 +228,11 @@ typedef struct mirt_stats {
     double ms_shade;
     double ms_accumulate;
     double ms_resolve;
+    double ms_tail;
+    uint64_t launches_tail;
+    uint64_t segments_tail; /* of `segments`, those issued by the tail kernel */
+    uint32_t tail_bounce;   /* bounce at which the last pass switched to the tail kernel (max_depth: never) */
+    uint32_t reserved;
 } mirt_stats;
 
 /* --------------------------------------------------------------- functions */

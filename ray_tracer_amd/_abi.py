@@ -114,6 +114,8 @@ class RenderOpts(C.Structure):
         ("tile_size", C.c_uint32),
         ("tile_count", C.c_uint32),
         ("tile_index", C.c_uint32),
+        ("tail_bounce", C.c_int32),
+        ("tail_paths", C.c_uint32),
     ]
 
 
@@ -131,6 +133,11 @@ class Stats(C.Structure):
         ("ms_shade", C.c_double),
         ("ms_accumulate", C.c_double),
         ("ms_resolve", C.c_double),
+        ("ms_tail", C.c_double),
+        ("launches_tail", C.c_uint64),
+        ("segments_tail", C.c_uint64),
+        ("tail_bounce", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

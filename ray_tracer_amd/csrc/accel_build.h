@@ -72,8 +72,9 @@ inline double half_area(const Box& b) {
     return std::isfinite(a) ? a : std::numeric_limits<double>::max();
 }
 
-inline uint32_t leaf_ref(const mirt_scene_desc* desc, uint32_t shape, bool gated) {
-    return REF_LEAF | (gated ? REF_GATED : 0u) | (desc->shapes[shape].kind << REF_KIND_SHIFT) | shape;
+// `tk` = TraverseKind of every shape (how the fast traversal tests it).
+inline uint32_t leaf_ref(const uint32_t* tk, uint32_t shape, bool gated) {
+    return REF_LEAF | (gated ? REF_GATED : 0u) | (tk[shape] << REF_KIND_SHIFT) | shape;
 }
 
 // Bounding box of a shape, used only to order and distance-prune leaf children of a
@@ -132,14 +133,47 @@ inline Box member_box(const mirt_bvh_member& m) {
 
 }  // namespace accel
 
+// TraverseKind and the ten traversal parameters of every shape (device_scene.h).
+inline void traversal_shapes(const mirt_scene_desc* desc, std::vector<uint32_t>* tk, std::vector<double>* params) {
+    tk->resize(desc->n_shapes);
+    params->assign((size_t)desc->n_shapes * TPARAMS_PER_SHAPE, 0.0);
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        const mirt_shape& s = desc->shapes[i];
+        double* p = params->data() + (size_t)i * TPARAMS_PER_SHAPE;
+        std::memcpy(p, s.f, sizeof s.f);
+        (*tk)[i] = s.kind;
+        if (s.kind == MIRT_SHAPE_SPHERE) {
+            (*tk)[i] = TK_SPHERE;
+            p[4] = p[5] = p[6] = 0.0;  // c1 - c0
+            p[7] = 0.0;                // ts
+            p[8] = 1.0;                // 1 / (te - ts)
+            p[9] = 0.0;
+        } else if (s.kind == MIRT_SHAPE_MOVING_SPHERE) {
+            const double movement_time = s.f[8] - s.f[7];  // hittable.rs:556
+            int exp = 0;
+            const bool pow2 = std::isnormal(movement_time) && std::frexp(movement_time, &exp) == 0.5 &&
+                              std::isnormal(1.0 / movement_time);
+            if (pow2) {
+                (*tk)[i] = TK_SPHERE;
+                for (int a = 0; a < 3; ++a) p[4 + a] = s.f[4 + a] - s.f[a];  // hittable.rs:558
+                p[7] = s.f[7];
+                p[8] = 1.0 / movement_time;  // exact
+                p[9] = 0.0;
+            } else {
+                (*tk)[i] = TK_MOVING_SPHERE;
+            }
+        }
+    }
+}
+
 // One DNode per BVHMember::Node, numbered breadth-first from the root.
-inline BuiltTree flatten_reference(const mirt_scene_desc* desc) {
+inline BuiltTree flatten_reference(const mirt_scene_desc* desc, const uint32_t* tk) {
     using namespace accel;
     BuiltTree t;
     const uint32_t nm = desc->n_nodes;
     const mirt_bvh_member& root = desc->nodes[nm - 1];
     if (root.is_leaf) {
-        t.root_ref = leaf_ref(desc, root.shape, false);
+        t.root_ref = leaf_ref(tk, root.shape, false);
         t.height = 1;
         return t;
     }
@@ -166,7 +200,7 @@ inline BuiltTree flatten_reference(const mirt_scene_desc* desc) {
         for (int c = 0; c < 2; ++c) {
             const mirt_bvh_member& ch = desc->nodes[kids[c]];
             if (ch.is_leaf) {
-                n.child[c] = leaf_ref(desc, ch.shape, false);
+                n.child[c] = leaf_ref(tk, ch.shape, false);
                 put_box(n, c, advisory_box(desc->shapes[ch.shape]));
             } else {
                 n.child[c] = node_of[kids[c]];
@@ -210,6 +244,7 @@ struct Group {
 
 struct Builder {
     const mirt_scene_desc* desc;
+    const uint32_t* tk;
     std::vector<Group>& groups;
     std::vector<DNode>& out;
     uint32_t max_height;
@@ -228,16 +263,15 @@ struct Builder {
     // more gates the shapes.
     Sub emit_group(const Group& g, uint32_t depth) {
         height_seen = std::max(height_seen, depth + 1);
-        if (g.n_shapes == 1) return Sub{leaf_ref(desc, g.shapes[0], true), g.box};
+        if (g.n_shapes == 1) return Sub{leaf_ref(tk, g.shapes[0], true), g.box};
         if (g.shapes[1] == g.shapes[0] + 1) {
-            const uint32_t ref = leaf_ref(desc, g.shapes[0], true) | REF_PAIR |
-                                 (desc->shapes[g.shapes[1]].kind << REF_KIND2_SHIFT);
+            const uint32_t ref = leaf_ref(tk, g.shapes[0], true) | REF_PAIR | (tk[g.shapes[1]] << REF_KIND2_SHIFT);
             return Sub{ref, g.box};
         }
         DNode n;
         std::memset(&n, 0, sizeof n);
         for (int c = 0; c < 2; ++c) {
-            n.child[c] = leaf_ref(desc, g.shapes[c], false);
+            n.child[c] = leaf_ref(tk, g.shapes[c], false);
             put_box(n, c, advisory_box(desc->shapes[g.shapes[c]]));
         }
         out.push_back(n);
@@ -304,14 +338,14 @@ struct Builder {
 }  // namespace accel
 
 // Surface-area-heuristic tree over the reference's leaf groups.  Requires boxes_nest(desc).
-inline BuiltTree regroup(const mirt_scene_desc* desc, uint32_t max_height) {
+inline BuiltTree regroup(const mirt_scene_desc* desc, const uint32_t* tk, uint32_t max_height) {
     using namespace accel;
     BuiltTree t;
     t.regrouped = true;
     const uint32_t nm = desc->n_nodes;
     const mirt_bvh_member& root = desc->nodes[nm - 1];
     if (root.is_leaf) {
-        t.root_ref = leaf_ref(desc, root.shape, false);
+        t.root_ref = leaf_ref(tk, root.shape, false);
         t.height = 1;
         return t;
     }
@@ -331,7 +365,7 @@ inline BuiltTree regroup(const mirt_scene_desc* desc, uint32_t max_height) {
         }
         groups.push_back(g);
     }
-    Builder b{desc, groups, t.nodes, max_height};
+    Builder b{desc, tk, groups, t.nodes, max_height};
     const Builder::Sub top = b.build(0, (uint32_t)groups.size(), 0);
     t.root_ref = top.ref;
     for (int a = 0; a < 3; ++a) {

@@ -154,10 +154,9 @@ __device__ __forceinline__ bool cube_hit(const double* __restrict__ f, const Ray
 }
 
 // Shape::hit (hittable.rs:625-635) reduced to what a closest-hit query keeps.
-__device__ __forceinline__ bool shape_hit(const DShape* __restrict__ shapes, uint32_t index, uint32_t kind,
-                                          const RayD& r, double dd, double t_min, double t_max, double* t_out,
-                                          int* side_out) {
-    const double* __restrict__ f = shapes[index].f;
+// `f` = the shape's parameters (DShape::f, in global memory or staged in LDS).
+__device__ __forceinline__ bool shape_hit_params(const double* __restrict__ f, uint32_t kind, const RayD& r, double dd,
+                                                 double t_min, double t_max, double* t_out, int* side_out) {
     *side_out = 0;
     switch (kind) {
         case MIRT_SHAPE_SPHERE: return sphere_hit(v3(f[0], f[1], f[2]), f[3], r, dd, t_min, t_max, t_out);
@@ -169,6 +168,27 @@ __device__ __forceinline__ bool shape_hit(const DShape* __restrict__ shapes, uin
             return sphere_hit(moving_center(f, r.time), f[3], r, dd, t_min, t_max, t_out);
         default: return false;
     }
+}
+
+// The same for the fast traversal: `p` = the shape's ten traversal parameters and `tk`
+// its TraverseKind (device_scene.h).
+__device__ __forceinline__ bool tshape_hit(const double* __restrict__ p, uint32_t tk, const RayD& r, double dd,
+                                           double t_min, double t_max, double* t_out, int* side_out) {
+    *side_out = 0;
+    if (tk == TK_SPHERE) {
+        // Moving::center (hittable.rs:550-561) with the division by a power of two turned into
+        // the multiplication by its exact reciprocal; a static sphere has p[4..6] = 0
+        const double frac = (r.time - p[7]) * p[8];
+        const V3 c = v3(p[0], p[1], p[2]) + frac * v3(p[4], p[5], p[6]);
+        return sphere_hit(c, p[3], r, dd, t_min, t_max, t_out);
+    }
+    return shape_hit_params(p, tk, r, dd, t_min, t_max, t_out, side_out);
+}
+
+__device__ __forceinline__ bool shape_hit(const DShape* __restrict__ shapes, uint32_t index, uint32_t kind,
+                                          const RayD& r, double dd, double t_min, double t_max, double* t_out,
+                                          int* side_out) {
+    return shape_hit_params(shapes[index].f, kind, r, dd, t_min, t_max, t_out, side_out);
 }
 
 struct HitRec {

@@ -14,8 +14,8 @@ namespace mirt {
 //   leaf        : bit 30 = gated: test the shapes only if the box stored beside this
 //                 reference passes the slab test
 //                 bit 29 = pair: two shapes, index and index + 1
-//                 bits 26..28 = MIRT_SHAPE_* kind of shape `index`
-//                 bits 23..25 = kind of shape `index + 1` (pair only)
+//                 bits 26..28 = TraverseKind of shape `index`
+//                 bits 23..25 = TraverseKind of shape `index + 1` (pair only)
 //                 bits 0..22  = index into the sorted shape array
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_GATED = 0x40000000u;
@@ -52,6 +52,26 @@ struct alignas(32) DShape {
 };
 static_assert(sizeof(DShape) == 96, "DShape is 96 bytes");
 
+// How the fast traversal tests a shape.  Same numbering as MIRT_SHAPE_* except that
+// TK_SPHERE also covers a moving sphere whose movement time (time_end - time_start) is a
+// power of two: dividing by it equals multiplying by its (exact) reciprocal, so
+//     center(time) = c0 + ((time - ts) * rcp) * (c1 - c0)
+// carries the bits of Moving::center (src/hittable.rs:550-561), and a static sphere is the
+// same formula with c1 - c0 = 0 (c0 + x * 0 = c0 for any finite x).  One code path for
+// every sphere of the usual scenes means no divergence between the two kinds.
+// Parameters of the fast traversal, ten doubles per shape (DScene::tparams):
+//   TK_SPHERE          {c0x, c0y, c0z, radius, c1x - c0x, c1y - c0y, c1z - c0z, ts, 1 / (te - ts)}
+//   every other kind   the shape's own parameters (mirt_shape.f)
+enum TraverseKind : uint32_t {
+    TK_SPHERE = 0,
+    TK_XY_RECT = 1,
+    TK_XZ_RECT = 2,
+    TK_YZ_RECT = 3,
+    TK_CUBE = 4,
+    TK_MOVING_SPHERE = 5  // movement time not a power of two: keeps the division
+};
+constexpr int TPARAMS_PER_SHAPE = 10;
+
 // Shade classes: paths are binned by this after each closest-hit query so that a
 // wave of the shade kernel runs one material/texture kind.
 enum ShadeClass : uint32_t {
@@ -75,6 +95,7 @@ constexpr int MAX_TREE_HEIGHT = 24;
 struct DScene {
     const DNode* nodes;              // inner nodes; root = nodes[root_ref] unless the root is a leaf
     const DShape* shapes;            // BVH-sorted order
+    const double* tparams;           // TPARAMS_PER_SHAPE doubles per shape, see TraverseKind
     const mirt_bvh_member* members;  // the reference's own member array (post-order, root last)
     const mirt_material* materials;
     const mirt_texture* textures;

@@ -45,7 +45,7 @@ struct Paths {
     uint8_t* cls_q;                              // shade class of live entry i (queue order)
     uint32_t* cls_queue;                         // SHADE_NUM_CLASSES queues of `capacity` slots
     uint32_t* counters;                          // see Counters
-    unsigned long long* segments;                // running total of closest-hit queries
+    unsigned long long* segments;                // [0] running total of closest-hit queries, [1] those of k_tail
     uint32_t capacity;
 };
 
@@ -58,7 +58,9 @@ struct Counters {
     __host__ __device__ uint32_t cls(uint32_t b, uint32_t c) const { return depth + 1 + b * SHADE_NUM_CLASSES + c; }
     // [D+1+8D .. D+1+9D)        work[b]     next unclaimed live entry of bounce b (fast extend kernel)
     __host__ __device__ uint32_t work(uint32_t b) const { return depth + 1 + depth * SHADE_NUM_CLASSES + b; }
-    __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES + depth; }
+    // [D+1+9D]                  tail        closest-hit queries of k_tail beyond its first bounce
+    __host__ __device__ uint32_t tail() const { return depth + 1 + depth * SHADE_NUM_CLASSES + depth; }
+    __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES + depth + 1; }
 };
 
 // The pixels one call renders: those idx in [pixel_begin, pixel_end) whose tile
@@ -97,6 +99,7 @@ struct RenderParams {
     double t_min, t_max;    // 0.001, +inf (renderer.rs:103)
     int use_bvh;
     int traversal;
+    uint32_t tail_bounce;   // bounce at which k_tail takes over in this pass (max_depth: it does not)
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
@@ -133,36 +136,52 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DScene sc, const mirt_ray* 
 }
 
 // ---- the fast traversal as a kernel ------------------------------------------------
-constexpr int TRAV_BLOCK = 512;  // 8 waves share one LDS copy of the tree
+// Workgroup size: 1024 threads (16 waves = 4 per SIMD, one workgroup per CU) when the
+// tree is staged in LDS -- one copy serves the most waves -- and 512 otherwise.
+constexpr int TRAV_BLOCK_LDS = 1024;
+constexpr int TRAV_BLOCK_GLOBAL = 512;
 
-// Dynamic LDS: [stack: levels x TRAV_BLOCK entries of StackT][nodes: n_nodes x 104 B].
-__host__ __device__ inline size_t trav_stack_bytes(uint32_t levels, size_t entry) {
-    return (((size_t)levels * TRAV_BLOCK * entry) + 15) & ~(size_t)15;
+// Dynamic LDS: [stack: levels x TBLOCK entries of StackT][nodes: n_nodes x 104 B][shapes: n_shapes x 80 B].
+__host__ __device__ inline size_t trav_stack_bytes(uint32_t levels, size_t entry, int tblock) {
+    return (((size_t)levels * tblock * entry) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t trav_nodes_bytes(uint32_t n_nodes) {
+    return (((size_t)n_nodes * NODE_LDS_BYTES) + 15) & ~(size_t)15;
 }
 
-template <class StackT, bool NODES_IN_LDS, class Io>
-__global__ __launch_bounds__(TRAV_BLOCK) void k_traverse(DScene sc, Io io, uint32_t* __restrict__ work_counter,
-                                                          double t_min, double t_max, uint32_t stack_levels) {
+template <int TBLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS, bool STATS, class Io>
+__global__ __launch_bounds__(TBLOCK) void k_traverse(DScene sc, Io io, uint32_t* __restrict__ work_counter, double t_min,
+                                                      double t_max, uint32_t stack_levels, uint32_t tuning,
+                                                      unsigned long long* stats) {
     extern __shared__ __align__(16) char smem[];
     const uint32_t n = io.count();
     // waves beyond the number of chunks can never get work: leave before staging anything
-    const uint32_t chunk = chunk_rays(n, gridDim.x * (TRAV_BLOCK / 64));
+    const uint32_t chunk = chunk_rays(n, gridDim.x * (TBLOCK / 64));
     const uint32_t chunks = (n + chunk - 1) / chunk;
-    if (blockIdx.x * (TRAV_BLOCK / 64) >= chunks) return;
+    if (blockIdx.x * (TBLOCK / 64) >= chunks) return;
     StackT* stack = reinterpret_cast<StackT*>(smem);
-    char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT));
+    char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), TBLOCK);
+    char* lds_shapes = lds_nodes + (NODES_IN_LDS ? trav_nodes_bytes(sc.n_nodes) : 0);
     if (NODES_IN_LDS) {
-        // copy the first 26 dwords (boxes + child references) of every 32-dword DNode
+        // the first 26 dwords (boxes + child references) of every 32-dword DNode
         const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.nodes);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
         const uint32_t words = sc.n_nodes * (NODE_LDS_BYTES / 4);
-        for (uint32_t w = threadIdx.x; w < words; w += TRAV_BLOCK) {
+        for (uint32_t w = threadIdx.x; w < words; w += TBLOCK) {
             const uint32_t node = w / (NODE_LDS_BYTES / 4), j = w % (NODE_LDS_BYTES / 4);
             dst[w] = src[node * (sizeof(DNode) / 4) + j];
         }
-        __syncthreads();
     }
-    traverse_persistent<TRAV_BLOCK, StackT, NODES_IN_LDS>(sc, io, work_counter, t_min, t_max, lds_nodes, stack);
+    if (SHAPES_IN_LDS) {
+        // the ten traversal parameters of every shape, as they lie in DScene::tparams
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.tparams);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_shapes);
+        const uint32_t words = sc.n_shapes * (SHAPE_LDS_BYTES / 4);
+        for (uint32_t w = threadIdx.x; w < words; w += TBLOCK) dst[w] = src[w];
+    }
+    if (NODES_IN_LDS || SHAPES_IN_LDS) __syncthreads();
+    const TraverseLds lds{lds_nodes, lds_shapes};
+    traverse_persistent<TBLOCK, StackT, NODES_IN_LDS, SHAPES_IN_LDS, STATS>(sc, io, work_counter, t_min, t_max, lds, stack, tuning, stats);
 }
 
 // Rays and hits as arrays of structs (the parity entry point).
@@ -345,6 +364,81 @@ __global__ __launch_bounds__(BLOCK) void k_bin(Paths P, RenderParams rp, uint32_
 }
 
 // ----------------------------------------------------------------------- shade
+// What becomes of a path at a hit (or a miss): renderer.rs:99-116 for one bounce.
+struct ShadeResult {
+    bool alive;     // the path goes on with the ray (origin, direction) and throughput `beta`
+    V3 origin, direction;
+    V3 beta;
+    V3 radiance;    // value of the finished path when !alive
+};
+
+// cls: shade class of the hit shape (SHADE_MISS: none).  `last`: this is the deepest bounce
+// allowed; what would be scattered is multiplied by color(.., 0) = 0 (renderer.rs:99-101).
+__device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls, const RayD& r, double hit_t, uint32_t hit_ref,
+                                                  const V3& beta, uint64_t stream, uint32_t bounce, bool last,
+                                                  const V3& background, const mirt_perlin* lds_tables, uint32_t n_staged) {
+    ShadeResult out;
+    out.alive = false;
+    out.radiance = v3(0.0, 0.0, 0.0);
+    if (cls == SHADE_MISS) {
+        out.radiance = beta * background;  // renderer.rs:114
+        return out;
+    }
+    const Surface h = surface_at(sc, r, hit_t, hit_ref & HIT_PRIM_MASK, (int)(hit_ref >> HIT_SIDE_SHIFT));
+    const mirt_material* __restrict__ m = sc.materials + h.material;
+    if (cls == SHADE_LIGHT) {
+        // material.rs:144-152: no scatter, emit = texture value
+        out.radiance = beta * texture_value(sc, m->texture, h, lds_tables, n_staged);
+        return out;
+    }
+    if (last) return out;
+    PathRng rng{stream, bounce + 1u, 0u};
+    V3 dir, attenuation;
+    bool scattered = true;
+    if (cls == SHADE_METAL) {  // material.rs:74-91
+        const V3 reflected = reflect(unit(r.d), h.normal);
+        dir = reflected + m->param * random_in_unit_sphere(rng);
+        scattered = dot(dir, h.normal) > 0.0;
+        attenuation = v3(m->albedo[0], m->albedo[1], m->albedo[2]);
+    } else if (cls == SHADE_DIELECTRIC) {  // material.rs:104-131
+        const double refraction_ratio = h.front_facing ? 1.0 / m->param : m->param;
+        const V3 unit_direction = unit(r.d);
+        const double cos_theta = fmin(dot(-unit_direction, h.normal), 1.0);
+        const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+        const bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        if (cannot_refract || schlick(cos_theta, refraction_ratio) > rng.random_double()) {
+            dir = reflect(unit_direction, h.normal);
+        } else {
+            dir = refract(unit_direction, h.normal, refraction_ratio);
+        }
+        attenuation = v3(1.0, 1.0, 1.0);
+    } else {  // the lambertian classes, material.rs:51-59
+        const V3 target = h.p + h.normal + random_in_unit_sphere(rng);
+        dir = target - h.p;
+        attenuation = texture_value(sc, m->texture, h, lds_tables, n_staged);
+    }
+    if (scattered) {
+        out.alive = true;
+        out.origin = h.p;
+        out.direction = dir;
+        out.beta = beta * attenuation;  // (emitted + attenuation) with emitted = 0, renderer.rs:107
+    }
+    return out;
+}
+
+// Perlin tables (9 KB each: 256 gradient vectors + 3 permutations) staged in LDS by the
+// kernels that shade.  The host pads DScene::perlins to PERLIN_STAGED readable tables.
+constexpr int PERLIN_STAGED = 2;
+
+template <int NTHREADS>
+__device__ __forceinline__ void stage_perlin(const DScene& sc, mirt_perlin* dst_tables) {
+    const uint32_t words = (uint32_t)(sizeof(mirt_perlin) / 4) * PERLIN_STAGED;
+    const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.perlins);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(dst_tables);
+    for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) dst[w] = src[w];
+    __syncthreads();
+}
+
 // One wave = 64 consecutive entries of ONE class queue.  The virtual index space
 // is the concatenation of the class queues, each padded to a multiple of 64.
 // Survivors are appended to the next live queue with one atomic per block step.
@@ -352,20 +446,10 @@ template <bool HAS_NOISE>
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParams rp, uint32_t bounce) {
     __shared__ uint32_t s_cnt[2][WAVES_PER_BLOCK];
     __shared__ uint32_t s_base[2];
-    // Perlin tables (9 KB each: 256 gradient vectors + 3 permutations) staged in LDS
-    constexpr int N_STAGED = HAS_NOISE ? 2 : 0;
-    __shared__ mirt_perlin s_perlin[HAS_NOISE ? N_STAGED : 1];
-    uint32_t n_staged = 0;
-    if (HAS_NOISE) {
-        n_staged = sc.perlins ? (uint32_t)N_STAGED : 0u;
-        // number of tables in the scene is not in DScene; the host passes at least
-        // N_STAGED readable tables when HAS_NOISE (it pads the array)
-        const uint32_t words = (uint32_t)(sizeof(mirt_perlin) / 4) * n_staged;
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.perlins);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(s_perlin);
-        for (uint32_t w = threadIdx.x; w < words; w += BLOCK) dst[w] = src[w];
-        __syncthreads();
-    }
+    __shared__ mirt_perlin s_perlin[HAS_NOISE ? PERLIN_STAGED : 1];
+    const uint32_t n_staged = HAS_NOISE && sc.perlins ? (uint32_t)PERLIN_STAGED : 0u;
+    if (n_staged) stage_perlin<BLOCK>(sc, s_perlin);
+    const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
 
     const Counters C{rp.max_depth};
     uint32_t cnt[SHADE_NUM_CLASSES], pref[SHADE_NUM_CLASSES + 1];
@@ -402,62 +486,26 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
         if (valid) {
             slot = P.cls_queue[(size_t)cls * P.capacity + first + lane];
             const V3 beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
-            V3 radiance = v3(0.0, 0.0, 0.0);
-            if (cls == SHADE_MISS) {
-                radiance = beta * background;  // renderer.rs:114
-            } else {
-                RayD r;
+            RayD r{};
+            double hit_t = 0.0;
+            uint32_t hit_ref = HIT_MISS;
+            uint64_t stream = 0;
+            if (cls != SHADE_MISS) {
                 r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
                 r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
                 r.time = P.time[slot];
-                const uint32_t ref = P.hit_ref[slot];
-                const Surface h =
-                    surface_at(sc, r, P.hit_t[slot], ref & HIT_PRIM_MASK, (int)(ref >> HIT_SIDE_SHIFT));
-                const mirt_material* __restrict__ m = sc.materials + h.material;
-                const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
-                if (cls == SHADE_LIGHT) {
-                    // material.rs:144-152: no scatter, emit = texture value
-                    radiance = beta * texture_value(sc, m->texture, h, lds_tables, n_staged);
-                } else if (!last) {
-                    // when this is the last bounce the path's value is multiplied by
-                    // color(.., 0) = 0 (renderer.rs:99-101): nothing to compute
-                    PathRng rng{P.stream[slot], bounce + 1u, 0u};
-                    V3 dir, attenuation;
-                    bool scattered = true;
-                    if (cls == SHADE_METAL) {  // material.rs:74-91
-                        const V3 reflected = reflect(unit(r.d), h.normal);
-                        dir = reflected + m->param * random_in_unit_sphere(rng);
-                        scattered = dot(dir, h.normal) > 0.0;
-                        attenuation = v3(m->albedo[0], m->albedo[1], m->albedo[2]);
-                    } else if (cls == SHADE_DIELECTRIC) {  // material.rs:104-131
-                        const double refraction_ratio = h.front_facing ? 1.0 / m->param : m->param;
-                        const V3 unit_direction = unit(r.d);
-                        const double cos_theta = fmin(dot(-unit_direction, h.normal), 1.0);
-                        const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-                        const bool cannot_refract = refraction_ratio * sin_theta > 1.0;
-                        if (cannot_refract || schlick(cos_theta, refraction_ratio) > rng.random_double()) {
-                            dir = reflect(unit_direction, h.normal);
-                        } else {
-                            dir = refract(unit_direction, h.normal, refraction_ratio);
-                        }
-                        attenuation = v3(1.0, 1.0, 1.0);
-                    } else {  // the lambertian classes, material.rs:51-59
-                        const V3 target = h.p + h.normal + random_in_unit_sphere(rng);
-                        dir = target - h.p;
-                        attenuation = texture_value(sc, m->texture, h, lds_tables, n_staged);
-                    }
-                    if (scattered) {
-                        alive = true;
-                        P.ox[slot] = h.p.x; P.oy[slot] = h.p.y; P.oz[slot] = h.p.z;
-                        P.dx[slot] = dir.x; P.dy[slot] = dir.y; P.dz[slot] = dir.z;
-                        // (emitted + attenuation) with emitted = 0, renderer.rs:107
-                        const V3 nb = beta * attenuation;
-                        P.bx[slot] = nb.x; P.by[slot] = nb.y; P.bz[slot] = nb.z;
-                    }
-                }
+                hit_t = P.hit_t[slot];
+                hit_ref = P.hit_ref[slot];
+                if (cls != SHADE_LIGHT && !last) stream = P.stream[slot];
             }
-            if (!alive) {
-                P.rr[slot] = radiance.x; P.rg[slot] = radiance.y; P.rb[slot] = radiance.z;
+            const ShadeResult s = shade_path(sc, cls, r, hit_t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
+            alive = s.alive;
+            if (alive) {
+                P.ox[slot] = s.origin.x; P.oy[slot] = s.origin.y; P.oz[slot] = s.origin.z;
+                P.dx[slot] = s.direction.x; P.dy[slot] = s.direction.y; P.dz[slot] = s.direction.z;
+                P.bx[slot] = s.beta.x; P.by[slot] = s.beta.y; P.bz[slot] = s.beta.z;
+            } else {
+                P.rr[slot] = s.radiance.x; P.rg[slot] = s.radiance.y; P.rb[slot] = s.radiance.z;
             }
         }
         // ---- append survivors: ballot per wave, one atomic per block step
@@ -478,6 +526,84 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
             qout[off + mbcnt_lt(mask)] = slot;
         }
     }
+}
+
+// ------------------------------------------------------------------------ tail
+// Every path still alive when bounce `bounce0` starts, followed to its end by one lane:
+// closest hit, shade, next bounce, in registers.  Deep bounces hold few paths (RTIOW: 1 % of
+// the paths reach bounce 10, some go on to bounce 50); a launch per bounce for them costs far
+// more in launch latency than in work.  Results do not depend on where the switch happens:
+// a path's random numbers are a function of (pixel, sample, bounce) alone.
+constexpr int TAIL_BLOCK = 256;
+
+template <class StackT, bool HAS_NOISE>
+__global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, Paths P, RenderParams rp, uint32_t bounce0) {
+    extern __shared__ __align__(16) char smem[];  // [level][TAIL_BLOCK] stack entries
+    __shared__ mirt_perlin s_perlin[HAS_NOISE ? PERLIN_STAGED : 1];
+    const uint32_t n_staged = HAS_NOISE && sc.perlins ? (uint32_t)PERLIN_STAGED : 0u;
+    if (n_staged) stage_perlin<TAIL_BLOCK>(sc, s_perlin);
+    const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
+    StackT* stack = reinterpret_cast<StackT*>(smem);
+    const TraverseLds lds{nullptr, nullptr};
+
+    const Counters C{rp.max_depth};
+    const uint32_t n = bounce0 == 0 ? rp.n_paths : P.counters[C.live(bounce0)];
+    const uint32_t* __restrict__ qin = P.live[bounce0 & 1];
+    uint32_t* __restrict__ work = P.counters + C.work(bounce0);
+    const V3 background = v3(rp.background[0], rp.background[1], rp.background[2]);
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+
+    bool have = false, exhausted = false;
+    uint32_t slot = 0, bounce = 0, extra_segments = 0;
+    RayD r{};
+    V3 beta = v3(0.0, 0.0, 0.0);
+    uint64_t stream = 0;
+    RayWalk<TAIL_BLOCK, StackT, false, false> walk;
+    for (;;) {
+        // lanes without a path take the next entries of the queue
+        const unsigned long long need = __ballot(!have);
+        if (need && !exhausted) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work, (uint32_t)__popcll(need));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t i = base + mbcnt_lt(need);
+            if (!have && i < n) {
+                slot = bounce0 == 0 ? i : qin[i];
+                r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
+                r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
+                r.time = P.time[slot];
+                beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
+                stream = P.stream[slot];
+                bounce = bounce0;
+                have = true;
+            }
+            exhausted = base + (uint32_t)__popcll(need) >= n;
+        }
+        if (__ballot(have) == 0) break;
+        traverse_wave(sc, have, r, rp.t_min, rp.t_max, lds, stack, tid, walk);
+        if (have) {
+            if (bounce != bounce0) ++extra_segments;
+            const HitRec h = walk.best;
+            uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS;
+            if (h.prim >= 0) {
+                cls = sc.shapes[h.prim].cls;
+                hit_ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
+            }
+            const bool last = bounce + 1 == rp.max_depth;
+            const ShadeResult s = shade_path(sc, cls, r, h.t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
+            if (s.alive) {
+                r.o = s.origin;
+                r.d = s.direction;
+                beta = s.beta;
+                ++bounce;
+            } else {
+                P.rr[slot] = s.radiance.x; P.rg[slot] = s.radiance.y; P.rb[slot] = s.radiance.z;
+                have = false;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) extra_segments += __shfl_xor(extra_segments, o);
+    if (lane == 0 && extra_segments) atomicAdd(P.counters + C.tail(), extra_segments);
 }
 
 // ------------------------------------------------------------------ accumulate
@@ -501,8 +627,12 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const Counters C{rp.max_depth};
         unsigned long long seg = rp.n_paths;
+        // live(b) stays zero for the bounces k_tail ran beyond its first; it counts those itself
         for (uint32_t b = 1; b < rp.max_depth; ++b) seg += P.counters[C.live(b)];
-        *P.segments += seg;
+        seg += P.counters[C.tail()];
+        P.segments[0] += seg;
+        if (rp.tail_bounce < rp.max_depth)
+            P.segments[1] += (rp.tail_bounce == 0 ? rp.n_paths : P.counters[C.live(rp.tail_bounce)]) + P.counters[C.tail()];
     }
 }
 

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -209,12 +210,15 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     }
     for (uint32_t i = 0; i < desc->n_textures; ++i) has_noise |= desc->textures[i].kind == MIRT_TEX_NOISE;
 
+    std::vector<uint32_t> tkinds;
+    std::vector<double> tparams;
+    traversal_shapes(desc, &tkinds, &tparams);
     BuiltTree tree;
     if (desc->nodes) {
         // The regrouped tree needs every Node box to contain its inner children's boxes
         // (true of any tree BoundingVolumeHierarchy::new builds); otherwise keep the
         // reference's own topology.
-        tree = boxes_nest(desc) ? regroup(desc, MAX_TREE_HEIGHT) : flatten_reference(desc);
+        tree = boxes_nest(desc) ? regroup(desc, tkinds.data(), MAX_TREE_HEIGHT) : flatten_reference(desc, tkinds.data());
         if (tree.height > (uint32_t)MAX_TREE_HEIGHT)
             return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", tree.height, MAX_TREE_HEIGHT);
         // the reference-order kernel walks the caller's own members: bound their depth too
@@ -262,6 +266,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
         }                                                                                                 \
     } while (0)
     DShape* d_shapes = nullptr;
+    double* d_tparams = nullptr;
     DNode* d_nodes = nullptr;
     mirt_bvh_member* d_members = nullptr;
     mirt_material* d_materials = nullptr;
@@ -269,6 +274,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     mirt_perlin* d_perlins = nullptr;
     mirt_image* d_images = nullptr;
     SCENE_TRY(upload(&d_shapes, shapes.data(), shapes.size()));
+    SCENE_TRY(upload(&d_tparams, tparams.data(), tparams.size()));
     SCENE_TRY(upload(&d_nodes, nodes.data(), nodes.size()));
     SCENE_TRY(upload(&d_members, desc->nodes, desc->nodes ? desc->n_nodes : 0));
     SCENE_TRY(upload(&d_materials, desc->materials, desc->n_materials));
@@ -285,6 +291,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     SCENE_TRY(upload(&d_images, images.data(), images.size()));
 #undef SCENE_TRY
     sc->d.shapes = d_shapes;
+    sc->d.tparams = d_tparams;
     sc->d.nodes = d_nodes;
     sc->d.members = d_members;
     sc->d.materials = d_materials;
@@ -339,63 +346,121 @@ static int grid_for(const mirt_scene* scene, size_t work_items, int blocks_per_c
 
 namespace {
 
-// How the fast traversal kernel is launched for one scene: stack entry width, whether
-// the tree is staged in LDS, dynamic LDS bytes and the persistent grid.
+// How the fast traversal kernel is launched for one scene: stack entry width, what is
+// staged in LDS, workgroup size, dynamic LDS bytes.
 struct TraversePlan {
     bool stack16 = true;
     bool nodes_in_lds = false;
+    bool shapes_in_lds = false;
+    int block = TRAV_BLOCK_GLOBAL;
     size_t lds_bytes = 0;
     uint32_t levels = 1;
 };
 
-// A block may use this much LDS and still leave room for a second block on the CU (160 KB).
-constexpr size_t TRAV_LDS_BUDGET = 78 * 1024;
+// One 1024-thread workgroup per CU may use this much of the CU's 160 KB of LDS.
+constexpr size_t TRAV_LDS_BUDGET = 150 * 1024;
 
 TraversePlan plan_traverse(const mirt_scene* scene) {
     TraversePlan p;
     p.levels = std::max<uint32_t>(scene->height, 1);
     p.stack16 = scene->d.n_nodes < 65536u;
-    const size_t stack = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4);
-    const size_t nodes = (size_t)scene->d.n_nodes * NODE_LDS_BYTES;
-    p.nodes_in_lds = scene->d.n_nodes > 0 && stack + nodes <= TRAV_LDS_BUDGET;
-    p.lds_bytes = stack + (p.nodes_in_lds ? nodes : 0);
+    const size_t entry = p.stack16 ? 2 : 4;
+    const size_t nodes = trav_nodes_bytes(scene->d.n_nodes);
+    const size_t shapes = (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
+    const size_t stack_lds = trav_stack_bytes(p.levels, entry, TRAV_BLOCK_LDS);
+    if (scene->d.n_nodes > 0 && stack_lds + nodes <= TRAV_LDS_BUDGET) {
+        p.nodes_in_lds = true;
+        p.block = TRAV_BLOCK_LDS;
+        p.lds_bytes = stack_lds + nodes;
+        if (p.lds_bytes + shapes <= TRAV_LDS_BUDGET) {
+            p.shapes_in_lds = true;
+            p.lds_bytes += shapes;
+        }
+    } else {
+        p.block = TRAV_BLOCK_GLOBAL;
+        p.lds_bytes = trav_stack_bytes(p.levels, entry, TRAV_BLOCK_GLOBAL);
+    }
     return p;
 }
 
-template <class StackT, bool LDS, class Io>
+template <int TBLOCK, class StackT, bool NLDS, bool SLDS, bool STATS, class Io>
 hipError_t launch_traverse_as(const mirt_scene* scene, const TraversePlan& plan, const Io& io, uint32_t* work_counter,
-                              double t_min, double t_max, hipStream_t stream) {
-    auto kernel = k_traverse<StackT, LDS, Io>;
-    // grid = every block the device can hold at once (persistent waves pull work themselves)
-    static thread_local const void* sized_for = nullptr;
-    static thread_local size_t sized_bytes = 0;
+                              double t_min, double t_max, hipStream_t stream, unsigned long long* stats = nullptr) {
+    auto kernel = k_traverse<TBLOCK, StackT, NLDS, SLDS, STATS, Io>;
+    // grid = every workgroup the device can hold at once (persistent waves pull work themselves)
+    static thread_local size_t sized_bytes = ~(size_t)0;
     static thread_local int per_cu = 1;
-    if (sized_for != (const void*)kernel || sized_bytes != plan.lds_bytes) {
+    if (sized_bytes != plan.lds_bytes) {
         if (plan.lds_bytes > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
             if (e != hipSuccess) return e;
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, TRAV_BLOCK, plan.lds_bytes) != hipSuccess || n <= 0) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, TBLOCK, plan.lds_bytes) != hipSuccess || n <= 0) n = 1;
         per_cu = std::min(n, 4);
-        sized_for = (const void*)kernel;
         sized_bytes = plan.lds_bytes;
     }
     const int grid = scene->cu_count * per_cu;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRAV_BLOCK), plan.lds_bytes, stream, scene->d, io, work_counter, t_min, t_max, plan.levels);
+    // development aid: MIRT_TRAV_TUNING overrides the scheduling parameters of the kernel
+    static const uint32_t tuning = [] {
+        const char* s = std::getenv("MIRT_TRAV_TUNING");
+        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : TUNING_DEFAULT;
+    }();
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(TBLOCK), plan.lds_bytes, stream, scene->d, io, work_counter, t_min, t_max, plan.levels, tuning, stats);
     return hipGetLastError();
+}
+
+template <class StackT, bool STATS, class Io>
+hipError_t launch_traverse_stack(const mirt_scene* scene, const TraversePlan& plan, const Io& io, uint32_t* work_counter,
+                                 double t_min, double t_max, hipStream_t stream, unsigned long long* stats) {
+    if (plan.nodes_in_lds && plan.shapes_in_lds)
+        return launch_traverse_as<TRAV_BLOCK_LDS, StackT, true, true, STATS>(scene, plan, io, work_counter, t_min, t_max, stream, stats);
+    if (plan.nodes_in_lds)
+        return launch_traverse_as<TRAV_BLOCK_LDS, StackT, true, false, STATS>(scene, plan, io, work_counter, t_min, t_max, stream, stats);
+    return launch_traverse_as<TRAV_BLOCK_GLOBAL, StackT, false, false, STATS>(scene, plan, io, work_counter, t_min, t_max, stream, stats);
 }
 
 template <class Io>
 hipError_t launch_traverse(const mirt_scene* scene, const Io& io, uint32_t* work_counter, double t_min, double t_max,
                            hipStream_t stream) {
     const TraversePlan plan = plan_traverse(scene);
-    if (plan.stack16) {
-        if (plan.nodes_in_lds) return launch_traverse_as<uint16_t, true>(scene, plan, io, work_counter, t_min, t_max, stream);
-        return launch_traverse_as<uint16_t, false>(scene, plan, io, work_counter, t_min, t_max, stream);
-    }
-    if (plan.nodes_in_lds) return launch_traverse_as<uint32_t, true>(scene, plan, io, work_counter, t_min, t_max, stream);
-    return launch_traverse_as<uint32_t, false>(scene, plan, io, work_counter, t_min, t_max, stream);
+    if (plan.stack16) return launch_traverse_stack<uint16_t, false>(scene, plan, io, work_counter, t_min, t_max, stream, nullptr);
+    return launch_traverse_stack<uint32_t, false>(scene, plan, io, work_counter, t_min, t_max, stream, nullptr);
+}
+
+// Development aid (MIRT_TRAV_STATS=1 in the environment): the same traversal with lane
+// utilisation counters, printed to stderr.  16-bit stacks only.
+hipError_t launch_traverse_with_stats(const mirt_scene* scene, const IntersectIo& io, uint32_t* work_counter, double t_min,
+                                      double t_max) {
+    const TraversePlan plan = plan_traverse(scene);
+    if (!plan.stack16) return hipErrorNotSupported;
+    unsigned long long* d_stats = nullptr;
+    hipError_t e = hipMalloc((void**)&d_stats, STAT_COUNT * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    (void)hipMemset(d_stats, 0, STAT_COUNT * sizeof(unsigned long long));
+    e = launch_traverse_stack<uint16_t, true>(scene, plan, io, work_counter, t_min, t_max, 0, d_stats);
+    unsigned long long h[STAT_COUNT] = {0};
+    if (e == hipSuccess) e = hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d_stats);
+    if (e == hipSuccess)
+        std::fprintf(stderr,
+                     "[mirt traverse stats] rays=%u nodes=%u lds_nodes=%d lds_shapes=%d block=%d levels=%u lds_bytes=%zu | outer=%llu | node iters=%llu lanes/iter=%.1f | "
+                     "leaf iters=%llu lanes/iter=%.1f | refill iters=%llu lanes/iter=%.1f | shape tests/ray=%.2f node visits/ray=%.2f\n",
+                     io.n, scene->d.n_nodes, (int)plan.nodes_in_lds, (int)plan.shapes_in_lds, plan.block, plan.levels, plan.lds_bytes, h[STAT_OUTER_ITERS], h[STAT_NODE_ITERS],
+                     h[STAT_NODE_ITERS] ? (double)h[STAT_NODE_LANES] / h[STAT_NODE_ITERS] : 0.0, h[STAT_LEAF_ITERS],
+                     h[STAT_LEAF_ITERS] ? (double)h[STAT_LEAF_LANES] / h[STAT_LEAF_ITERS] : 0.0, h[STAT_REFILL_ITERS],
+                     h[STAT_REFILL_ITERS] ? (double)h[STAT_REFILL_LANES] / h[STAT_REFILL_ITERS] : 0.0,
+                     (double)h[STAT_SHAPE_TESTS] / io.n, (double)h[STAT_NODE_LANES] / io.n);
+    if (e == hipSuccess && h[STAT_CYC_TOTAL])
+        std::fprintf(stderr,
+                     "[mirt traverse stats] wave clocks: refill %.1f%% (%.0f per refill) | node loop %.1f%% (%.0f per visit) | leaf %.1f%% "
+                     "(%.0f per phase) | store %.1f%% | other %.1f%%\n",
+                     100.0 * h[STAT_CYC_REFILL] / h[STAT_CYC_TOTAL], (double)h[STAT_CYC_REFILL] / std::max(1ull, h[STAT_REFILL_ITERS]),
+                     100.0 * h[STAT_CYC_NODE] / h[STAT_CYC_TOTAL], (double)h[STAT_CYC_NODE] / std::max(1ull, h[STAT_NODE_ITERS]),
+                     100.0 * h[STAT_CYC_LEAF] / h[STAT_CYC_TOTAL], (double)h[STAT_CYC_LEAF] / std::max(1ull, h[STAT_LEAF_ITERS]),
+                     100.0 * h[STAT_CYC_STORE] / h[STAT_CYC_TOTAL],
+                     100.0 * (1.0 - (double)(h[STAT_CYC_REFILL] + h[STAT_CYC_NODE] + h[STAT_CYC_LEAF] + h[STAT_CYC_STORE]) / h[STAT_CYC_TOTAL]));
+    return e;
 }
 
 }  // namespace
@@ -422,7 +487,9 @@ int mirt_intersect_device(const mirt_scene* scene, const mirt_ray* d_rays, size_
             HIP_TRY(arena.alloc(&d_work, (size_t)1));
             HIP_TRY(hipMemsetAsync(d_work, 0, sizeof(uint32_t), 0));
             IntersectIo io{d_rays, d_hits, (uint32_t)n};
-            HIP_TRY(launch_traverse(scene, io, d_work, t_min, t_max, 0));
+            const char* want_stats = std::getenv("MIRT_TRAV_STATS");
+            if (want_stats && want_stats[0] == '1') HIP_TRY(launch_traverse_with_stats(scene, io, d_work, t_min, t_max));
+            else HIP_TRY(launch_traverse(scene, io, d_work, t_min, t_max, 0));
             break;
         }
     }
@@ -480,12 +547,12 @@ namespace {
 
 struct EventTimer {
     // Pairs of HIP events around kernel launches of one pass, summed per class after the pass.
-    enum Class { RAYGEN = 0, EXTEND, BIN, SHADE, ACCUMULATE, N_CLASSES };
+    enum Class { RAYGEN = 0, EXTEND, BIN, SHADE, ACCUMULATE, TAIL, N_CLASSES };
     bool enabled = false;
     std::vector<hipEvent_t> pool;
     std::vector<int> cls_of_pair;
     size_t used = 0;
-    double ms[N_CLASSES] = {0, 0, 0, 0, 0};
+    double ms[N_CLASSES] = {0, 0, 0, 0, 0, 0};
 
     hipError_t begin(hipStream_t s, int cls) {
         if (!enabled) return hipSuccess;
@@ -526,6 +593,47 @@ int blocks_per_cu(K kernel, int fallback) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0) != hipSuccess || n <= 0) return fallback;
     return std::min(n, 8);
+}
+
+// The tail kernel's launch shape for one scene.
+struct TailPlan {
+    bool stack16 = true;
+    size_t lds_bytes = 0;
+    int per_cu = 1;
+};
+
+
+template <class StackT, bool NOISE>
+int tail_occupancy(size_t lds_bytes) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tail<StackT, NOISE>, TAIL_BLOCK, lds_bytes) != hipSuccess || n <= 0) n = 1;
+    return std::min(n, 8);
+}
+
+TailPlan plan_tail(const mirt_scene* scene) {
+    TailPlan p;
+    p.stack16 = scene->d.n_nodes < 65536u;
+    p.lds_bytes = trav_stack_bytes(std::max<uint32_t>(scene->height, 1), p.stack16 ? 2 : 4, TAIL_BLOCK);
+    if (p.stack16) p.per_cu = scene->has_noise ? tail_occupancy<uint16_t, true>(p.lds_bytes) : tail_occupancy<uint16_t, false>(p.lds_bytes);
+    else p.per_cu = scene->has_noise ? tail_occupancy<uint32_t, true>(p.lds_bytes) : tail_occupancy<uint32_t, false>(p.lds_bytes);
+    return p;
+}
+
+// expected: paths that will probably enter (the kernel copes with any number).
+hipError_t launch_tail(const mirt_scene* scene, const TailPlan& plan, const Paths& P, const RenderParams& rp, uint32_t bounce,
+                       uint32_t expected, hipStream_t stream) {
+    // few paths: spread them over as many waves as there are, a path's bounces are sequential
+    const size_t want = ((size_t)expected + TAIL_BLOCK - 1) / TAIL_BLOCK;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)scene->cu_count * plan.per_cu));
+    const dim3 g(grid), b(TAIL_BLOCK);
+    if (plan.stack16) {
+        if (scene->has_noise) hipLaunchKernelGGL((k_tail<uint16_t, true>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
+        else hipLaunchKernelGGL((k_tail<uint16_t, false>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
+    } else {
+        if (scene->has_noise) hipLaunchKernelGGL((k_tail<uint32_t, true>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
+        else hipLaunchKernelGGL((k_tail<uint32_t, false>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
+    }
+    return hipGetLastError();
 }
 
 int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
@@ -594,9 +702,9 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     HIP_TRY(arena.alloc(&P.cls_queue, (size_t)capacity * SHADE_NUM_CLASSES));
     const Counters C{max_depth};
     HIP_TRY(arena.alloc(&P.counters, (size_t)C.total()));
-    HIP_TRY(arena.alloc(&P.segments, (size_t)1));
+    HIP_TRY(arena.alloc(&P.segments, (size_t)2));
     hipStream_t stream = 0;
-    HIP_TRY(hipMemsetAsync(P.segments, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(P.segments, 0, 2 * sizeof(unsigned long long), stream));
 
     RenderParams rp;
     std::memset(&rp, 0, sizeof rp);
@@ -621,15 +729,30 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     }
     const int occ_shade = scene->has_noise ? blocks_per_cu(k_shade<true>, 2) : blocks_per_cu(k_shade<false>, 4);
 
+    // ---- where the per-bounce launches hand over to the tail kernel
+    const TailPlan tail = plan_tail(scene);
+    const bool tail_allowed = mode == MODE_FAST && o.tail_bounce >= 0;
+    // default: hand over once half of a pass's paths have ended (measured on RTIOW: any threshold
+    // between 25 % and 70 % picks bounce 2 and renders 1.8x as fast as never handing over)
+    uint32_t tail_paths = o.tail_paths ? o.tail_paths : std::max<uint32_t>(capacity / 2, 1);
+    if (const char* s = std::getenv("MIRT_TAIL_PATHS")) tail_paths = (uint32_t)std::strtoul(s, nullptr, 0);  // development aid
+    uint32_t tail_bounce = max_depth;         // max_depth = never
+    bool probing = false;                     // first pass of an automatic call: read the live counts back
+    uint32_t tail_estimate = tail_paths;      // paths expected to enter the tail kernel (sizes its grid)
+    if (tail_allowed && o.tail_bounce > 0) tail_bounce = std::min<uint32_t>((uint32_t)o.tail_bounce, max_depth);
+    if (tail_allowed && o.tail_bounce == 0) probing = true;
+    if (tail_allowed && o.tail_bounce > 0) tail_estimate = capacity;
+
     EventTimer timer;
     timer.enabled = o.profile != 0;
-    uint64_t passes = 0, launches_extend = 0, launches_shade = 0;
+    uint64_t passes = 0, launches_extend = 0, launches_shade = 0, launches_tail = 0;
 
     for (uint32_t s0 = o.sample_begin; s0 < o.sample_end; s0 += per_pass) {
         rp.sample_base = s0;
         rp.n_samples = std::min(per_pass, o.sample_end - s0);
         rp.n_paths = n_pixels * rp.n_samples;
         HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)C.total() * sizeof(uint32_t), stream));
+        rp.tail_bounce = max_depth;
 
         HIP_TRY(timer.begin(stream, EventTimer::RAYGEN));
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(scene, rp.n_paths, 8)), dim3(BLOCK), 0, stream, P, rp);
@@ -639,6 +762,25 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         const int grid_shade = grid_for(scene, rp.n_paths, occ_shade);
         const int grid_bin = (int)std::max<size_t>(1, std::min<size_t>(((size_t)rp.n_paths + BIN_TILE - 1) / BIN_TILE, (size_t)scene->cu_count * 8));
         for (uint32_t bounce = 0; bounce < max_depth; ++bounce) {
+            if (probing && bounce > 0) {
+                // one small read-back per bounce, first pass only: how many paths are left?
+                uint32_t live = 0;
+                HIP_TRY(hipMemcpyAsync(&live, P.counters + C.live(bounce), sizeof live, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (live <= tail_paths) {
+                    tail_bounce = bounce;
+                    tail_estimate = std::max<uint32_t>(live, 1);
+                    probing = false;
+                }
+            }
+            if (bounce >= tail_bounce) {
+                rp.tail_bounce = bounce;
+                HIP_TRY(timer.begin(stream, EventTimer::TAIL));
+                HIP_TRY(launch_tail(scene, tail, P, rp, bounce, tail_estimate, stream));
+                HIP_TRY(timer.end(stream));
+                ++launches_tail;
+                break;
+            }
             HIP_TRY(timer.begin(stream, EventTimer::EXTEND));
             switch (mode) {
                 case MODE_LIST: hipLaunchKernelGGL(k_extend<MODE_LIST>, dim3(grid_extend), dim3(BLOCK), 0, stream, scene->d, P, rp, bounce); break;
@@ -669,16 +811,18 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
             HIP_TRY(timer.collect());
         }
         ++passes;
+        probing = false;  // paths that never thin out: stay with a launch per bounce
     }
-    unsigned long long segments = 0;
-    HIP_TRY(hipMemcpyAsync(&segments, P.segments, sizeof segments, hipMemcpyDeviceToHost, stream));
+    unsigned long long segments[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(segments, P.segments, sizeof segments, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
 
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->samples = (uint64_t)n_pixels * n_samples_total;
-        stats->segments = segments;
+        stats->segments = segments[0];
+        stats->segments_tail = segments[1];
         stats->passes = passes;
         stats->launches_extend = launches_extend;
         stats->launches_shade = launches_shade;
@@ -687,6 +831,9 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         stats->ms_bin = timer.ms[EventTimer::BIN];
         stats->ms_shade = timer.ms[EventTimer::SHADE];
         stats->ms_accumulate = timer.ms[EventTimer::ACCUMULATE];
+        stats->ms_tail = timer.ms[EventTimer::TAIL];
+        stats->launches_tail = launches_tail;
+        stats->tail_bounce = tail_bounce;
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     }
     return MIRT_OK;
