@@ -11,8 +11,11 @@ split by interleaved rows across ranks (no data-path collective; rank 0 gathers 
 rendered rows), or with --split sample every rank renders all pixels for spp/N of the
 samples and the f64 accumulation images are summed with one RCCL reduce.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (extend =
-closest-hit queries) against HBM with the algorithmic bytes of DESIGN.md;
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with
+the algorithmic bytes of DESIGN.md: the path kernel (whole paths in registers, 24 bytes of
+radiance out per sample) in the default mode, the closest-hit kernel of the per-bounce
+pipeline with --handover -1.  Neither is bound by HBM: `roofline.valu_f64` prices the same
+kernel against the f64 vector ALU, which is what limits it.
 `cpu_baseline` times the CPU oracle (a C++ restatement of the reference algorithm,
 not the reference itself: no Rust toolchain exists here) on a bounded sample of the
 same workload on the host cores of the same box.
@@ -28,6 +31,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# bytes the path kernel moves per sample: the finished path's radiance (3 f64) out
+PATHS_BYTES_PER_SAMPLE = 24
 # bytes one closest-hit query moves through the ray queues in HBM: ray in (7 f64) + hit record out (t, ref)
 EXTEND_BYTES_PER_SEGMENT = 56 + 16
 # bytes per path segment over the whole extend + bin + shade step, and per sample for the accumulator
@@ -48,6 +53,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--split", default="tile", choices=["tile", "sample"])
     ap.add_argument("--paths-per-pass", type=int, default=0)
+    ap.add_argument("--handover", type=int, default=0,
+                    help="mirt_render_opts.handover_bounce: 0 = path kernel from the camera ray (default), N = launches per "
+                         "bounce below bounce N, -1 = launches per bounce throughout, -2 = probe")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work to spend on the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
     return ap.parse_args()
@@ -127,7 +135,8 @@ def main():
         if args.split == "tile" or world_size == 1:
             # rows interleaved over ranks: tile = one row, rank r owns rows r, r + N, ...
             _, st = api.render_world(cfg.background, scene, cam, W, H, spp, paths_per_pass=args.paths_per_pass,
-                                     profile=profile, out=out, return_stats=True, tiles=(W, world_size, rank))
+                                     profile=profile, out=out, return_stats=True, tiles=(W, world_size, rank),
+                                     handover=(args.handover, 0))
             if world_size > 1:
                 mine = torch.from_numpy(np.ascontiguousarray(out[rank::world_size]))
                 if rank == 0:
@@ -143,7 +152,7 @@ def main():
             lo = rank * spp // world_size
             hi = (rank + 1) * spp // world_size
             st = api.render_accumulate(scene, cam, cfg.background, W, H, spp, accum.data_ptr(), sample_range=(lo, hi),
-                                       paths_per_pass=args.paths_per_pass, profile=profile)
+                                       paths_per_pass=args.paths_per_pass, profile=profile, handover=(args.handover, 0))
             dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
             if rank == 0:
                 api.resolve(accum.data_ptr(), W, H, spp, out=out)
@@ -163,10 +172,11 @@ def main():
         elapsed = float(t.item())
 
     # sums over ranks of what each rank's library calls report
-    keys = ("samples", "segments", "segments_tail", "launches_extend", "launches_tail", "ms_extend", "ms_shade", "ms_bin",
-            "ms_raygen", "ms_accumulate", "ms_tail")
+    keys = ("samples", "segments", "segments_paths", "launches_extend", "launches_paths", "ms_extend", "ms_shade", "ms_bin",
+            "ms_raygen", "ms_accumulate", "ms_paths")
     local = torch.tensor([sum(st[k] for st in step_stats) for k in keys], dtype=torch.float64, device=dev)
-    local_max_extend = torch.tensor([sum(st["ms_extend"] for st in step_stats)], dtype=torch.float64, device=dev)
+    dominant = "ms_paths" if step_stats[-1]["handover_bounce"] == 0 else "ms_extend"
+    local_max_extend = torch.tensor([sum(st[dominant] for st in step_stats)], dtype=torch.float64, device=dev)
     if world_size > 1:
         dist.all_reduce(local, op=dist.ReduceOp.SUM)
         dist.all_reduce(local_max_extend, op=dist.ReduceOp.MAX)
@@ -197,19 +207,38 @@ def main():
                 "split": args.split if world_size > 1 else "none",
                 "traversal": "fast (near-first, distance-pruned, reference hit/miss decisions)",
             },
-            "tail": {"bounce": int(step_stats[-1]["tail_bounce"]), "segments_frac": tot["segments_tail"] / max(1.0, tot["segments"])},
+            "handover": {"bounce": int(step_stats[-1]["handover_bounce"]),
+                         "path_kernel_segments_frac": tot["segments_paths"] / max(1.0, tot["segments"])},
             "mrays_per_s": tot["segments"] / elapsed / 1e6,
             "segments_per_sample": tot["segments"] / samples,
         }
-        if profile and tot["ms_extend"] > 0:
+        if profile and dominant == "ms_paths" and tot["ms_paths"] > 0:
+            launches = tot["launches_paths"]
+            avg_ms = tot["ms_paths"] / launches
+            achieved = samples * PATHS_BYTES_PER_SAMPLE / launches / (avg_ms * 1e-3) / 1e9
+            result["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_paths (whole paths, one per lane: camera ray, closest hit, shade, next bounce, in registers)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_unit": PATHS_BYTES_PER_SAMPLE,
+                "units_per_launch": samples / launches,
+                "avg_launch_ms": avg_ms,
+                "launches": launches,
+                "note": "not HBM-bound by design: see valu_f64 for the resource that limits it",
+            }
+        elif profile and tot["ms_extend"] > 0:
             launches = tot["launches_extend"]
             avg_ms = tot["ms_extend"] / launches
-            extend_segments = tot["segments"] - tot["segments_tail"]  # the tail kernel's are not this kernel's
+            extend_segments = tot["segments"] - tot["segments_paths"]  # the path kernel's are not this kernel's
             bytes_per_launch = extend_segments * EXTEND_BYTES_PER_SEGMENT / launches
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             result["roofline"] = {
                 "bound": "hbm",
-                "kernel": "k_extend (closest-hit query of every live path of one bounce)",
+                "kernel": "k_traverse (closest-hit query of every live path of one bounce)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -222,6 +251,7 @@ def main():
                 "pipeline_gbs": (tot["segments"] * PIPELINE_BYTES_PER_SEGMENT + samples * PIPELINE_BYTES_PER_SAMPLE)
                                 / elapsed / 1e9,
             }
+        if profile:
             result["kernel_ms"] = {k[3:]: tot[k] / world_size for k in keys if k.startswith("ms_")}
         if args.cpu_seconds > 0 and world_size == 1:
             base = cpu_baseline(cfg, world, args.cpu_seconds)
@@ -229,11 +259,12 @@ def main():
             if "roofline" in result:
                 # FP64 VALU view of the same kernel: operations the reference algorithm needs for
                 # these rays (27 per box test, 33 per leaf test, counted by the oracle) per second
-                ops = tot["segments"] * (27 * base["box_tests_per_segment"] + 33 * base["leaf_tests_per_segment"])
+                kernel_segments = tot["segments_paths"] if dominant == "ms_paths" else tot["segments"] - tot["segments_paths"]
+                ops = kernel_segments * (27 * base["box_tests_per_segment"] + 33 * base["leaf_tests_per_segment"])
                 result["roofline"]["valu_f64"] = {
                     "achieved_tops": ops / (local_max_extend.item() * 1e-3) / 1e12,
                     "peak_tops": FP64_VALU_PEAK_TOPS,
-                    "note": "reference-traversal op count of these rays / extend kernel time",
+                    "note": "reference-traversal op count of this kernel's rays (shading not counted) / its time",
                 }
                 result["roofline"]["valu_f64"]["frac"] = result["roofline"]["valu_f64"]["achieved_tops"] / FP64_VALU_PEAK_TOPS
         print(json.dumps(result))

@@ -189,6 +189,12 @@ enum {
     MIRT_TRAVERSE_FAST = 1
 };
 
+/* Values of mirt_render_opts.handover_bounce below zero. */
+enum {
+    MIRT_HANDOVER_NEVER = -1,
+    MIRT_HANDOVER_PROBE = -2
+};
+
 typedef struct mirt_render_opts {
     uint32_t struct_size;    /* = sizeof(mirt_render_opts) */
     int32_t device;          /* HIP device ordinal; -1 = current device */
@@ -198,7 +204,9 @@ typedef struct mirt_render_opts {
     uint32_t pixel_end;      /* 0 = W*H */
     uint32_t sample_begin;   /* render samples s in [sample_begin, sample_end) of 0..spp */
     uint32_t sample_end;     /* 0 = spp */
-    uint32_t paths_per_pass; /* target number of paths resident per pass; 0 = default */
+    uint32_t paths_per_pass; /* target number of paths per pass; 0 = default (2^26 when the path kernel
+                              * runs from the camera ray, 24 B of device memory per path; 2^23 otherwise,
+                              * 165 B per path) */
     int32_t profile;         /* 1 = time each kernel class with HIP events (fills mirt_stats.ms_*) */
     /* Tile split across devices: of the pixel range, cut into tiles of tile_size
      * consecutive pixels, only tiles t with t % tile_count == tile_index are
@@ -206,13 +214,19 @@ typedef struct mirt_render_opts {
     uint32_t tile_size;
     uint32_t tile_count;
     uint32_t tile_index;
-    /* Scheduling only, never results: from bounce `tail_bounce` on, the paths still alive are
-     * followed to their end by one kernel instead of three launches per bounce (few paths
-     * live that long, and a launch costs more than their work).  0 = automatic: the first
-     * bounce that at most `tail_paths` paths reach (measured during the first pass of the
-     * call); N > 0 = bounce N; < 0 = never.  Fast traversal only. */
-    int32_t tail_bounce;
-    uint32_t tail_paths;     /* threshold of the automatic choice; 0 = default (half the paths of a pass) */
+    /* Scheduling only, never results.  Two ways to run a path's bounces exist: one lane
+     * follows the path from its ray at bounce N to its end inside one kernel ("path kernel"),
+     * or every bounce is three launches (closest hit, sort by material, shade) over the
+     * queue of paths still alive.  handover_bounce = N chooses where the first takes over:
+     *   0 (default)           from the camera ray: no launches per bounce at all (fastest)
+     *   N > 0                 launches per bounce for bounces < N, path kernel from bounce N
+     *   MIRT_HANDOVER_NEVER   launches per bounce throughout
+     *   MIRT_HANDOVER_PROBE   like N, N = the first bounce that at most handover_paths paths
+     *                         reach (read back during the first pass of the call)
+     * The path kernel uses the fast traversal; with MIRT_TRAVERSE_REFERENCE or use_bvh = 0
+     * the setting is ignored and every bounce is launched. */
+    int32_t handover_bounce;
+    uint32_t handover_paths; /* threshold of MIRT_HANDOVER_PROBE; 0 = half the paths of a pass */
 } mirt_render_opts;
 
 typedef struct mirt_stats {
@@ -228,10 +242,10 @@ typedef struct mirt_stats {
     double ms_shade;
     double ms_accumulate;
     double ms_resolve;
-    double ms_tail;
-    uint64_t launches_tail;
-    uint64_t segments_tail; /* of `segments`, those issued by the tail kernel */
-    uint32_t tail_bounce;   /* bounce at which the last pass switched to the tail kernel (max_depth: never) */
+    double ms_paths;           /* the path kernel */
+    uint64_t launches_paths;
+    uint64_t segments_paths;   /* of `segments`, those issued by the path kernel */
+    uint32_t handover_bounce;  /* bounce at which the last pass went over to the path kernel (max_depth: never) */
     uint32_t reserved;
 } mirt_stats;
 

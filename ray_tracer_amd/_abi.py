@@ -114,8 +114,8 @@ class RenderOpts(C.Structure):
         ("tile_size", C.c_uint32),
         ("tile_count", C.c_uint32),
         ("tile_index", C.c_uint32),
-        ("tail_bounce", C.c_int32),
-        ("tail_paths", C.c_uint32),
+        ("handover_bounce", C.c_int32),
+        ("handover_paths", C.c_uint32),
     ]
 
 
@@ -133,10 +133,10 @@ class Stats(C.Structure):
         ("ms_shade", C.c_double),
         ("ms_accumulate", C.c_double),
         ("ms_resolve", C.c_double),
-        ("ms_tail", C.c_double),
-        ("launches_tail", C.c_uint64),
-        ("segments_tail", C.c_uint64),
-        ("tail_bounce", C.c_uint32),
+        ("ms_paths", C.c_double),
+        ("launches_paths", C.c_uint64),
+        ("segments_paths", C.c_uint64),
+        ("handover_bounce", C.c_uint32),
         ("reserved", C.c_uint32),
     ]
 
@@ -146,6 +146,7 @@ SHAPE_SPHERE, SHAPE_XY_RECT, SHAPE_XZ_RECT, SHAPE_YZ_RECT, SHAPE_CUBE, SHAPE_MOV
 MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_DIFFUSE_LIGHT = range(4)
 TEX_CONSTANT, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(4)
 TRAVERSE_REFERENCE, TRAVERSE_FAST = 0, 1
+HANDOVER_NEVER, HANDOVER_PROBE = -1, -2
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = 0, -1, -2, -3, -4, -5
 
 # name -> (restype, argtypes) for every symbol the headers declare

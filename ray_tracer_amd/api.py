@@ -152,7 +152,7 @@ class Scene:
 
 
 def make_opts(use_bvh=True, traversal=abi.TRAVERSE_FAST, pixel_range=(0, 0), sample_range=(0, 0), paths_per_pass=0,
-              profile=False, device=-1, tiles=(0, 1, 0), tail=(0, 0)):
+              profile=False, device=-1, tiles=(0, 1, 0), handover=(0, 0)):
     o = abi.RenderOpts()
     o.struct_size = C.sizeof(abi.RenderOpts)
     o.device = device
@@ -163,7 +163,7 @@ def make_opts(use_bvh=True, traversal=abi.TRAVERSE_FAST, pixel_range=(0, 0), sam
     o.paths_per_pass = paths_per_pass
     o.profile = int(bool(profile))
     o.tile_size, o.tile_count, o.tile_index = tiles
-    o.tail_bounce, o.tail_paths = tail
+    o.handover_bounce, o.handover_paths = handover
     return o
 
 
@@ -174,14 +174,14 @@ def stats_dict(s):
 def render_world(background, world, camera, screen_width, screen_height, antialias_iterations, render_parallel=True,
                  use_bounding_volume=True, seed=0x5EED0002, max_depth=MAX_DEPTH, traversal=abi.TRAVERSE_FAST,
                  pixel_range=(0, 0), paths_per_pass=0, profile=False, out=None, return_stats=False, tiles=(0, 1, 0),
-                 tail=(0, 0)):
+                 handover=(0, 0)):
     """render_world (src/renderer.rs:9-62): (H, W, 3) uint8, top row first.
 
     `world` is a Scene (already on the device) or a World (uploaded for this call).
     `render_parallel` selects rayon vs a serial loop in the reference and has no
     meaning on the device.  `tiles` = (tile_size, tile_count, tile_index) renders only
     this device's share of a tile split; the other pixels of `out` are left untouched.
-    `tail` = (tail_bounce, tail_paths) of mirt_render_opts: scheduling only, never results.
+    `handover` = (handover_bounce, handover_paths) of mirt_render_opts: scheduling only, never results.
     """
     del render_parallel
     own = None
@@ -192,7 +192,7 @@ def render_world(background, world, camera, screen_width, screen_height, antiali
         if out is None:
             out = np.zeros((screen_height, screen_width, 3), dtype=np.uint8)
         assert out.dtype == np.uint8 and out.size == screen_width * screen_height * 3 and out.flags.c_contiguous
-        opts = make_opts(use_bounding_volume, traversal, pixel_range, (0, 0), paths_per_pass, profile, tiles=tiles, tail=tail)
+        opts = make_opts(use_bounding_volume, traversal, pixel_range, (0, 0), paths_per_pass, profile, tiles=tiles, handover=handover)
         stats = abi.Stats()
         _check(abi.libmirt().mirt_render(scene.handle, C.byref(camera.c), _vec3(background), screen_width,
                                          screen_height, antialias_iterations, max_depth, seed, C.byref(opts),
@@ -205,9 +205,9 @@ def render_world(background, world, camera, screen_width, screen_height, antiali
 
 def render_accumulate(scene, camera, background, width, height, spp, d_accum_ptr, seed=0x5EED0002, max_depth=MAX_DEPTH,
                       use_bvh=True, traversal=abi.TRAVERSE_FAST, pixel_range=(0, 0), sample_range=(0, 0),
-                      paths_per_pass=0, profile=False, tiles=(0, 1, 0), tail=(0, 0)):
+                      paths_per_pass=0, profile=False, tiles=(0, 1, 0), handover=(0, 0)):
     """Adds the radiance of a sample range into a DEVICE f64 image (address `d_accum_ptr`)."""
-    opts = make_opts(use_bvh, traversal, pixel_range, sample_range, paths_per_pass, profile, tiles=tiles, tail=tail)
+    opts = make_opts(use_bvh, traversal, pixel_range, sample_range, paths_per_pass, profile, tiles=tiles, handover=handover)
     stats = abi.Stats()
     _check(abi.libmirt().mirt_render_accumulate(scene.handle, C.byref(camera.c), _vec3(background), width, height, spp,
                                                 max_depth, seed, C.byref(opts), C.c_void_p(d_accum_ptr),

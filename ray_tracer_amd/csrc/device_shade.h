@@ -196,6 +196,7 @@ __device__ __forceinline__ double perlin_turbulence(const double* __restrict__ v
     V3 current_p = p;
     double weight = 1.0;
     double accumulator = 0.0;
+#pragma nounroll
     for (int i = 0; i < depth; ++i) {
         accumulator += weight * perlin_noise(vecs, perm_x, perm_y, perm_z, current_p);
         weight *= 0.5;
@@ -222,7 +223,14 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, cons
         const uint32_t kind = t->kind;
         if (kind == MIRT_TEX_CONSTANT) return v3(t->color[0], t->color[1], t->color[2]);
         if (kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
-            const double sines = sin(10.0 * h.p.x) * sin(10.0 * h.p.y) * sin(10.0 * h.p.z);
+            // one sin() at a time: three inlined side by side cost ~100 more registers
+            double sines = 1.0;
+#pragma nounroll
+            for (int a = 0; a < 3; ++a) {
+                const double x = a == 0 ? h.p.x : (a == 1 ? h.p.y : h.p.z);
+                const double s = sin(10.0 * x);
+                sines = a == 0 ? s : sines * s;
+            }
             tex = (sines < 0.0) ? t->odd : t->even;
             continue;
         }

@@ -45,7 +45,7 @@ struct Paths {
     uint8_t* cls_q;                              // shade class of live entry i (queue order)
     uint32_t* cls_queue;                         // SHADE_NUM_CLASSES queues of `capacity` slots
     uint32_t* counters;                          // see Counters
-    unsigned long long* segments;                // [0] running total of closest-hit queries, [1] those of k_tail
+    unsigned long long* segments;                // [0] running total of closest-hit queries, [1] those of k_paths
     uint32_t capacity;
 };
 
@@ -58,9 +58,7 @@ struct Counters {
     __host__ __device__ uint32_t cls(uint32_t b, uint32_t c) const { return depth + 1 + b * SHADE_NUM_CLASSES + c; }
     // [D+1+8D .. D+1+9D)        work[b]     next unclaimed live entry of bounce b (fast extend kernel)
     __host__ __device__ uint32_t work(uint32_t b) const { return depth + 1 + depth * SHADE_NUM_CLASSES + b; }
-    // [D+1+9D]                  tail        closest-hit queries of k_tail beyond its first bounce
-    __host__ __device__ uint32_t tail() const { return depth + 1 + depth * SHADE_NUM_CLASSES + depth; }
-    __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES + depth + 1; }
+    __host__ __device__ uint32_t total() const { return depth + 1 + depth * SHADE_NUM_CLASSES + depth; }
 };
 
 // The pixels one call renders: those idx in [pixel_begin, pixel_end) whose tile
@@ -99,7 +97,7 @@ struct RenderParams {
     double t_min, t_max;    // 0.001, +inf (renderer.rs:103)
     int use_bvh;
     int traversal;
-    uint32_t tail_bounce;   // bounce at which k_tail takes over in this pass (max_depth: it does not)
+    uint32_t handover;      // bounce at which k_paths takes over in this pass (max_depth: it does not)
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
@@ -149,6 +147,29 @@ __host__ __device__ inline size_t trav_nodes_bytes(uint32_t n_nodes) {
     return (((size_t)n_nodes * NODE_LDS_BYTES) + 15) & ~(size_t)15;
 }
 
+// Copies the tree's nodes and the shapes' traversal parameters into LDS (whole workgroup).
+template <int NTHREADS, bool NODES, bool SHAPES>
+__device__ __forceinline__ void stage_tree(const DScene& sc, char* lds_nodes, char* lds_shapes) {
+    if (NODES) {
+        // the first 26 dwords (boxes + child references) of every 32-dword DNode
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.nodes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
+        const uint32_t words = sc.n_nodes * (NODE_LDS_BYTES / 4);
+        for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) {
+            const uint32_t node = w / (NODE_LDS_BYTES / 4), j = w % (NODE_LDS_BYTES / 4);
+            dst[w] = src[node * (sizeof(DNode) / 4) + j];
+        }
+    }
+    if (SHAPES) {
+        // the ten traversal parameters of every shape, as they lie in DScene::tparams
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.tparams);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_shapes);
+        const uint32_t words = sc.n_shapes * (SHAPE_LDS_BYTES / 4);
+        for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) dst[w] = src[w];
+    }
+    if (NODES || SHAPES) __syncthreads();
+}
+
 template <int TBLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS, bool STATS, class Io>
 __global__ __launch_bounds__(TBLOCK) void k_traverse(DScene sc, Io io, uint32_t* __restrict__ work_counter, double t_min,
                                                       double t_max, uint32_t stack_levels, uint32_t tuning,
@@ -162,24 +183,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(DScene sc, Io io, uint32_t*
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), TBLOCK);
     char* lds_shapes = lds_nodes + (NODES_IN_LDS ? trav_nodes_bytes(sc.n_nodes) : 0);
-    if (NODES_IN_LDS) {
-        // the first 26 dwords (boxes + child references) of every 32-dword DNode
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.nodes);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
-        const uint32_t words = sc.n_nodes * (NODE_LDS_BYTES / 4);
-        for (uint32_t w = threadIdx.x; w < words; w += TBLOCK) {
-            const uint32_t node = w / (NODE_LDS_BYTES / 4), j = w % (NODE_LDS_BYTES / 4);
-            dst[w] = src[node * (sizeof(DNode) / 4) + j];
-        }
-    }
-    if (SHAPES_IN_LDS) {
-        // the ten traversal parameters of every shape, as they lie in DScene::tparams
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.tparams);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_shapes);
-        const uint32_t words = sc.n_shapes * (SHAPE_LDS_BYTES / 4);
-        for (uint32_t w = threadIdx.x; w < words; w += TBLOCK) dst[w] = src[w];
-    }
-    if (NODES_IN_LDS || SHAPES_IN_LDS) __syncthreads();
+    stage_tree<TBLOCK, NODES_IN_LDS, SHAPES_IN_LDS>(sc, lds_nodes, lds_shapes);
     const TraverseLds lds{lds_nodes, lds_shapes};
     traverse_persistent<TBLOCK, StackT, NODES_IN_LDS, SHAPES_IN_LDS, STATS>(sc, io, work_counter, t_min, t_max, lds, stack, tuning, stats);
 }
@@ -528,23 +532,37 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
     }
 }
 
-// ------------------------------------------------------------------------ tail
-// Every path still alive when bounce `bounce0` starts, followed to its end by one lane:
-// closest hit, shade, next bounce, in registers.  Deep bounces hold few paths (RTIOW: 1 % of
-// the paths reach bounce 10, some go on to bounce 50); a launch per bounce for them costs far
-// more in launch latency than in work.  Results do not depend on where the switch happens:
-// a path's random numbers are a function of (pixel, sample, bounce) alone.
-constexpr int TAIL_BLOCK = 256;
+// ----------------------------------------------------------------------- paths
+// Whole paths, one per lane: camera ray (or the ray a path has when bounce `bounce0` starts),
+// closest hit, shade, next bounce ... until the path ends, all in registers; the lane then
+// takes the next path.  Nothing but the finished path's radiance goes to memory.
+// Measured on RTIOW against a launch per bounce over sorted queues of live paths (extend /
+// bin / shade, kept below): 2.3x the samples per second.  Deep bounces hold few paths (1 % of
+// them reach bounce 10, some go on to 50), a launch for them costs more in latency than in
+// work, and the queues' 200 bytes per path and bounce of HBM traffic buy less coherence than
+// they cost.  Results do not depend on the bounce at which this kernel takes over: a path's
+// random numbers are a function of (pixel, sample, bounce) alone.
+constexpr int PATHS_BLOCK = 256;
+// bits 0-7: as in traverse_persistent; bits 8-15: lanes waiting to be shaded that trigger
+// shading; bits 16-23: empty lanes that trigger a refill from the queue
+constexpr uint32_t PATHS_TUNING_DEFAULT = 2u | (48u << 8) | (16u << 16);
 
-template <class StackT, bool HAS_NOISE>
-__global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, Paths P, RenderParams rp, uint32_t bounce0) {
-    extern __shared__ __align__(16) char smem[];  // [level][TAIL_BLOCK] stack entries
+#ifndef MIRT_PATHS_WAVES
+#define MIRT_PATHS_WAVES 2  // waves per SIMD the register allocation of k_paths aims at
+#endif
+template <class StackT, bool HAS_NOISE, bool TREE_IN_LDS>
+__global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_PATHS_WAVES))) void k_paths(DScene sc, Paths P, RenderParams rp, uint32_t bounce0, uint32_t stack_levels, uint32_t tuning) {
+    // dynamic LDS: [level][PATHS_BLOCK] stack entries, then (TREE_IN_LDS) nodes and shape parameters
+    extern __shared__ __align__(16) char smem[];
     __shared__ mirt_perlin s_perlin[HAS_NOISE ? PERLIN_STAGED : 1];
     const uint32_t n_staged = HAS_NOISE && sc.perlins ? (uint32_t)PERLIN_STAGED : 0u;
-    if (n_staged) stage_perlin<TAIL_BLOCK>(sc, s_perlin);
+    if (n_staged) stage_perlin<PATHS_BLOCK>(sc, s_perlin);
     const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
     StackT* stack = reinterpret_cast<StackT*>(smem);
-    const TraverseLds lds{nullptr, nullptr};
+    char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
+    char* lds_shapes = lds_nodes + trav_nodes_bytes(sc.n_nodes);
+    stage_tree<PATHS_BLOCK, TREE_IN_LDS, TREE_IN_LDS>(sc, lds_nodes, lds_shapes);
+    const TraverseLds lds{lds_nodes, lds_shapes};
 
     const Counters C{rp.max_depth};
     const uint32_t n = bounce0 == 0 ? rp.n_paths : P.counters[C.live(bounce0)];
@@ -553,57 +571,104 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, Paths P, RenderP
     const V3 background = v3(rp.background[0], rp.background[1], rp.background[2]);
     const uint32_t tid = threadIdx.x, lane = lane_id();
 
+    // A lane is empty (!have), traversing (have, walk not finished) or waiting to be shaded
+    // (have, walk finished).  Per trip the wave refills empty lanes, then runs the piece of
+    // code -- node visits, shape tests, shading -- that enough lanes are waiting for.
     bool have = false, exhausted = false;
     uint32_t slot = 0, bounce = 0, extra_segments = 0;
-    RayD r{};
     V3 beta = v3(0.0, 0.0, 0.0);
     uint64_t stream = 0;
-    RayWalk<TAIL_BLOCK, StackT, false, false> walk;
+    RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS> walk;
+    walk.reset();
+    const int stay = (int)(tuning & 0xFFu), shade_at = (int)((tuning >> 8) & 0xFFu);
+    const int refill_at = (int)((tuning >> 16) & 0xFFu);
     for (;;) {
-        // lanes without a path take the next entries of the queue
         const unsigned long long need = __ballot(!have);
-        if (need && !exhausted) {
+        // one queue access (a global atomic) serves many lanes: wait until enough are empty
+        if (!exhausted && (__popcll(need) >= refill_at || need == ~0ull)) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(work, (uint32_t)__popcll(need));
             base = __builtin_amdgcn_readfirstlane(base);
             const uint32_t i = base + mbcnt_lt(need);
             if (!have && i < n) {
-                slot = bounce0 == 0 ? i : qin[i];
-                r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
-                r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
-                r.time = P.time[slot];
-                beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
-                stream = P.stream[slot];
+                RayD r;
+                if (bounce0 == 0) {
+                    // slot i = sample (sample_base + i / n_pixels) of the (i % n_pixels)-th pixel, as in k_raygen
+                    slot = i;
+                    const uint32_t idx = rp.px.idx(slot % rp.n_pixels);
+                    PathRng rng{mirt_rng_stream(rp.seed, idx, rp.sample_base + slot / rp.n_pixels), 0u, 0u};
+                    r = camera_ray(rp.cam, rp.width, rp.height, idx, rng);
+                    beta = v3(1.0, 1.0, 1.0);
+                    stream = rng.stream;
+                } else {
+                    slot = qin[i];
+                    r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
+                    r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
+                    r.time = P.time[slot];
+                    beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
+                    stream = P.stream[slot];
+                }
                 bounce = bounce0;
                 have = true;
+                walk.begin(sc, r, rp.t_min, rp.t_max);
             }
             exhausted = base + (uint32_t)__popcll(need) >= n;
         }
-        if (__ballot(have) == 0) break;
-        traverse_wave(sc, have, r, rp.t_min, rp.t_max, lds, stack, tid, walk);
-        if (have) {
-            if (bounce != bounce0) ++extra_segments;
-            const HitRec h = walk.best;
-            uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS;
-            if (h.prim >= 0) {
-                cls = sc.shapes[h.prim].cls;
-                hit_ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
+        const int n_node = __popcll(__ballot(have && walk.wants_node()));
+        const int n_leaf = __popcll(__ballot(have && walk.wants_leaf()));
+        const int n_shade = __popcll(__ballot(have && walk.finished()));
+        if (n_node + n_leaf + n_shade == 0) {
+            if (exhausted) break;  // no path in flight and the queue is drained
+            continue;              // every lane is empty: the next trip refills
+        }
+        if (n_shade >= shade_at || n_node + n_leaf == 0) {
+            if (have && walk.finished()) {
+                if (bounce != bounce0) ++extra_segments;
+                const HitRec h = walk.best;
+                uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS;
+                if (h.prim >= 0) {
+                    cls = sc.shapes[h.prim].cls;
+                    hit_ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
+                }
+                const bool last = bounce + 1 == rp.max_depth;
+                const ShadeResult s = shade_path(sc, cls, walk.r, h.t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
+                if (s.alive) {
+                    RayD r;
+                    r.o = s.origin;
+                    r.d = s.direction;
+                    r.time = walk.r.time;
+                    beta = s.beta;
+                    ++bounce;
+                    walk.begin(sc, r, rp.t_min, rp.t_max);
+                } else {
+                    P.rr[slot] = s.radiance.x; P.rg[slot] = s.radiance.y; P.rb[slot] = s.radiance.z;
+                    have = false;
+                    walk.reset();
+                }
             }
-            const bool last = bounce + 1 == rp.max_depth;
-            const ShadeResult s = shade_path(sc, cls, r, h.t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
-            if (s.alive) {
-                r.o = s.origin;
-                r.d = s.direction;
-                beta = s.beta;
-                ++bounce;
-            } else {
-                P.rr[slot] = s.radiance.x; P.rg[slot] = s.radiance.y; P.rb[slot] = s.radiance.z;
-                have = false;
-            }
+            continue;
+        }
+        const int enough = max(1, ((n_node + n_leaf) * stay) >> 3);
+        if (n_leaf > n_node) {
+            int n_now;
+            do {
+                if (have && walk.wants_leaf()) walk.leaf_step(sc, lds, rp.t_min, rp.t_max);
+                n_now = __popcll(__ballot(have && walk.wants_leaf()));
+            } while (n_now >= enough);
+        } else {
+            int n_now;
+            do {
+                if (have && walk.wants_node()) walk.node_step(sc, lds, stack, tid, rp.t_min, rp.t_max);
+                n_now = __popcll(__ballot(have && walk.wants_node()));
+            } while (n_now >= enough);
         }
     }
     for (int o = 32; o > 0; o >>= 1) extra_segments += __shfl_xor(extra_segments, o);
-    if (lane == 0 && extra_segments) atomicAdd(P.counters + C.tail(), extra_segments);
+    if (lane == 0 && extra_segments) {
+        // (k_accumulate counts the segments of this kernel's first bounce with those of the queues)
+        atomicAdd(P.segments + 0, (unsigned long long)extra_segments);
+        atomicAdd(P.segments + 1, (unsigned long long)extra_segments);
+    }
 }
 
 // ------------------------------------------------------------------ accumulate
@@ -627,12 +692,11 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const Counters C{rp.max_depth};
         unsigned long long seg = rp.n_paths;
-        // live(b) stays zero for the bounces k_tail ran beyond its first; it counts those itself
+        // live(b) stays zero for the bounces k_paths ran beyond its first; it adds those itself
         for (uint32_t b = 1; b < rp.max_depth; ++b) seg += P.counters[C.live(b)];
-        seg += P.counters[C.tail()];
-        P.segments[0] += seg;
-        if (rp.tail_bounce < rp.max_depth)
-            P.segments[1] += (rp.tail_bounce == 0 ? rp.n_paths : P.counters[C.live(rp.tail_bounce)]) + P.counters[C.tail()];
+        atomicAdd(P.segments + 0, seg);
+        if (rp.handover < rp.max_depth)
+            atomicAdd(P.segments + 1, (unsigned long long)(rp.handover == 0 ? rp.n_paths : P.counters[C.live(rp.handover)]));
     }
 }
 

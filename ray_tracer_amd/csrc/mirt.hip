@@ -547,7 +547,7 @@ namespace {
 
 struct EventTimer {
     // Pairs of HIP events around kernel launches of one pass, summed per class after the pass.
-    enum Class { RAYGEN = 0, EXTEND, BIN, SHADE, ACCUMULATE, TAIL, N_CLASSES };
+    enum Class { RAYGEN = 0, EXTEND, BIN, SHADE, ACCUMULATE, PATHS, N_CLASSES };
     bool enabled = false;
     std::vector<hipEvent_t> pool;
     std::vector<int> cls_of_pair;
@@ -595,45 +595,66 @@ int blocks_per_cu(K kernel, int fallback) {
     return std::min(n, 8);
 }
 
-// The tail kernel's launch shape for one scene.
-struct TailPlan {
+// The path kernel's launch shape for one scene.
+struct PathsPlan {
     bool stack16 = true;
+    bool tree_in_lds = false;
     size_t lds_bytes = 0;
+    uint32_t levels = 1;
     int per_cu = 1;
+    const void* kernel = nullptr;
 };
 
-
-template <class StackT, bool NOISE>
-int tail_occupancy(size_t lds_bytes) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tail<StackT, NOISE>, TAIL_BLOCK, lds_bytes) != hipSuccess || n <= 0) n = 1;
-    return std::min(n, 8);
+template <class StackT, bool NOISE, bool TREE>
+void paths_kernel_for(PathsPlan* p) {
+    p->kernel = (const void*)k_paths<StackT, NOISE, TREE>;
 }
 
-TailPlan plan_tail(const mirt_scene* scene) {
-    TailPlan p;
+hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
+    PathsPlan p;
+    p.levels = std::max<uint32_t>(scene->height, 1);
     p.stack16 = scene->d.n_nodes < 65536u;
-    p.lds_bytes = trav_stack_bytes(std::max<uint32_t>(scene->height, 1), p.stack16 ? 2 : 4, TAIL_BLOCK);
-    if (p.stack16) p.per_cu = scene->has_noise ? tail_occupancy<uint16_t, true>(p.lds_bytes) : tail_occupancy<uint16_t, false>(p.lds_bytes);
-    else p.per_cu = scene->has_noise ? tail_occupancy<uint32_t, true>(p.lds_bytes) : tail_occupancy<uint32_t, false>(p.lds_bytes);
-    return p;
+    const size_t stack = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4, PATHS_BLOCK);
+    const size_t tree = trav_nodes_bytes(scene->d.n_nodes) + (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
+    const size_t fixed = scene->has_noise ? sizeof(mirt_perlin) * PERLIN_STAGED : 0;
+    // two workgroups per CU (the kernel's registers allow no more) must fit with their own copy
+    p.tree_in_lds = scene->d.n_nodes > 0 && 2 * (stack + tree + fixed) <= TRAV_LDS_BUDGET;
+    p.lds_bytes = stack + (p.tree_in_lds ? tree : 0);
+    if (p.stack16) {
+        if (scene->has_noise) p.tree_in_lds ? paths_kernel_for<uint16_t, true, true>(&p) : paths_kernel_for<uint16_t, true, false>(&p);
+        else p.tree_in_lds ? paths_kernel_for<uint16_t, false, true>(&p) : paths_kernel_for<uint16_t, false, false>(&p);
+    } else {
+        if (scene->has_noise) p.tree_in_lds ? paths_kernel_for<uint32_t, true, true>(&p) : paths_kernel_for<uint32_t, true, false>(&p);
+        else p.tree_in_lds ? paths_kernel_for<uint32_t, false, true>(&p) : paths_kernel_for<uint32_t, false, false>(&p);
+    }
+    if (p.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(p.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, p.kernel, PATHS_BLOCK, p.lds_bytes) != hipSuccess || n <= 0) n = 1;
+    p.per_cu = std::min(n, 8);
+    *out = p;
+    return hipSuccess;
 }
 
 // expected: paths that will probably enter (the kernel copes with any number).
-hipError_t launch_tail(const mirt_scene* scene, const TailPlan& plan, const Paths& P, const RenderParams& rp, uint32_t bounce,
+hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Paths& P, const RenderParams& rp, uint32_t bounce,
                        uint32_t expected, hipStream_t stream) {
     // few paths: spread them over as many waves as there are, a path's bounces are sequential
-    const size_t want = ((size_t)expected + TAIL_BLOCK - 1) / TAIL_BLOCK;
+    const size_t want = ((size_t)expected + PATHS_BLOCK - 1) / PATHS_BLOCK;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)scene->cu_count * plan.per_cu));
-    const dim3 g(grid), b(TAIL_BLOCK);
-    if (plan.stack16) {
-        if (scene->has_noise) hipLaunchKernelGGL((k_tail<uint16_t, true>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
-        else hipLaunchKernelGGL((k_tail<uint16_t, false>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
-    } else {
-        if (scene->has_noise) hipLaunchKernelGGL((k_tail<uint32_t, true>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
-        else hipLaunchKernelGGL((k_tail<uint32_t, false>), g, b, plan.lds_bytes, stream, scene->d, P, rp, bounce);
-    }
-    return hipGetLastError();
+    // development aid: MIRT_PATHS_TUNING overrides the scheduling parameters of the kernel
+    static const uint32_t tuning_default = [] {
+        const char* s = std::getenv("MIRT_PATHS_TUNING");
+        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : PATHS_TUNING_DEFAULT;
+    }();
+    DScene sc = scene->d;
+    Paths paths = P;
+    RenderParams params = rp;
+    uint32_t levels = plan.levels, tuning = tuning_default;
+    void* args[] = {&sc, &paths, &params, &bounce, &levels, &tuning};
+    return hipLaunchKernel(plan.kernel, dim3(grid), dim3(PATHS_BLOCK), args, plan.lds_bytes, stream);
 }
 
 int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
@@ -681,7 +702,19 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         return MIRT_OK;
     }
     const uint32_t n_samples_total = o.sample_end - o.sample_begin;
-    const uint64_t target = o.paths_per_pass ? o.paths_per_pass : (1ull << 23);
+
+    // ---- where the launches per bounce hand over to the path kernel (mirt_render_opts.handover_bounce)
+    uint32_t handover = max_depth;  // max_depth = never
+    bool probing = false;           // MIRT_HANDOVER_PROBE: read the live counts back during the first pass
+    if (mode == MODE_FAST) {
+        if (o.handover_bounce >= 0) handover = std::min<uint32_t>((uint32_t)o.handover_bounce, max_depth);
+        else if (o.handover_bounce == MIRT_HANDOVER_PROBE) probing = true;
+        else if (o.handover_bounce != MIRT_HANDOVER_NEVER)
+            return fail(MIRT_ERR_INVALID_ARGUMENT, "bad handover_bounce %d", o.handover_bounce);
+    }
+    const bool from_start = handover == 0;  // no queues of live paths, no per-path state but the radiance
+
+    const uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 26) : (1ull << 23));
     uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, target / n_pixels));
     const uint64_t capacity64 = (uint64_t)n_pixels * per_pass;
     if (capacity64 > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "pass of %llu paths is too large", (unsigned long long)capacity64);
@@ -692,14 +725,19 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     Paths P;
     std::memset(&P, 0, sizeof P);
     P.capacity = capacity;
-    double** f64_arrays[] = {&P.ox, &P.oy, &P.oz, &P.dx, &P.dy, &P.dz, &P.time, &P.bx, &P.by, &P.bz, &P.hit_t, &P.rr, &P.rg, &P.rb};
-    for (double** a : f64_arrays) HIP_TRY(arena.alloc(a, (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.hit_ref, (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.stream, (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.live[0], (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.live[1], (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.cls_q, (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.cls_queue, (size_t)capacity * SHADE_NUM_CLASSES));
+    HIP_TRY(arena.alloc(&P.rr, (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.rg, (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.rb, (size_t)capacity));
+    if (!from_start) {
+        double** f64_arrays[] = {&P.ox, &P.oy, &P.oz, &P.dx, &P.dy, &P.dz, &P.time, &P.bx, &P.by, &P.bz, &P.hit_t};
+        for (double** a : f64_arrays) HIP_TRY(arena.alloc(a, (size_t)capacity));
+        HIP_TRY(arena.alloc(&P.hit_ref, (size_t)capacity));
+        HIP_TRY(arena.alloc(&P.stream, (size_t)capacity));
+        HIP_TRY(arena.alloc(&P.live[0], (size_t)capacity));
+        HIP_TRY(arena.alloc(&P.live[1], (size_t)capacity));
+        HIP_TRY(arena.alloc(&P.cls_q, (size_t)capacity));
+        HIP_TRY(arena.alloc(&P.cls_queue, (size_t)capacity * SHADE_NUM_CLASSES));
+    }
     const Counters C{max_depth};
     HIP_TRY(arena.alloc(&P.counters, (size_t)C.total()));
     HIP_TRY(arena.alloc(&P.segments, (size_t)2));
@@ -729,34 +767,27 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     }
     const int occ_shade = scene->has_noise ? blocks_per_cu(k_shade<true>, 2) : blocks_per_cu(k_shade<false>, 4);
 
-    // ---- where the per-bounce launches hand over to the tail kernel
-    const TailPlan tail = plan_tail(scene);
-    const bool tail_allowed = mode == MODE_FAST && o.tail_bounce >= 0;
-    // default: hand over once half of a pass's paths have ended (measured on RTIOW: any threshold
-    // between 25 % and 70 % picks bounce 2 and renders 1.8x as fast as never handing over)
-    uint32_t tail_paths = o.tail_paths ? o.tail_paths : std::max<uint32_t>(capacity / 2, 1);
-    if (const char* s = std::getenv("MIRT_TAIL_PATHS")) tail_paths = (uint32_t)std::strtoul(s, nullptr, 0);  // development aid
-    uint32_t tail_bounce = max_depth;         // max_depth = never
-    bool probing = false;                     // first pass of an automatic call: read the live counts back
-    uint32_t tail_estimate = tail_paths;      // paths expected to enter the tail kernel (sizes its grid)
-    if (tail_allowed && o.tail_bounce > 0) tail_bounce = std::min<uint32_t>((uint32_t)o.tail_bounce, max_depth);
-    if (tail_allowed && o.tail_bounce == 0) probing = true;
-    if (tail_allowed && o.tail_bounce > 0) tail_estimate = capacity;
+    PathsPlan paths_plan;
+    if (mode == MODE_FAST) HIP_TRY(plan_paths(scene, &paths_plan));
+    uint32_t handover_paths = o.handover_paths ? o.handover_paths : std::max<uint32_t>(capacity / 2, 1);
+    uint32_t paths_estimate = capacity;  // paths expected to enter the path kernel (sizes its grid)
 
     EventTimer timer;
     timer.enabled = o.profile != 0;
-    uint64_t passes = 0, launches_extend = 0, launches_shade = 0, launches_tail = 0;
+    uint64_t passes = 0, launches_extend = 0, launches_shade = 0, launches_paths = 0;
 
     for (uint32_t s0 = o.sample_begin; s0 < o.sample_end; s0 += per_pass) {
         rp.sample_base = s0;
         rp.n_samples = std::min(per_pass, o.sample_end - s0);
         rp.n_paths = n_pixels * rp.n_samples;
         HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)C.total() * sizeof(uint32_t), stream));
-        rp.tail_bounce = max_depth;
+        rp.handover = max_depth;
 
-        HIP_TRY(timer.begin(stream, EventTimer::RAYGEN));
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(scene, rp.n_paths, 8)), dim3(BLOCK), 0, stream, P, rp);
-        HIP_TRY(timer.end(stream));
+        if (!from_start) {
+            HIP_TRY(timer.begin(stream, EventTimer::RAYGEN));
+            hipLaunchKernelGGL(k_raygen, dim3(grid_for(scene, rp.n_paths, 8)), dim3(BLOCK), 0, stream, P, rp);
+            HIP_TRY(timer.end(stream));
+        }
 
         const int grid_extend = grid_for(scene, rp.n_paths, occ_extend);
         const int grid_shade = grid_for(scene, rp.n_paths, occ_shade);
@@ -767,18 +798,18 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
                 uint32_t live = 0;
                 HIP_TRY(hipMemcpyAsync(&live, P.counters + C.live(bounce), sizeof live, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
-                if (live <= tail_paths) {
-                    tail_bounce = bounce;
-                    tail_estimate = std::max<uint32_t>(live, 1);
+                if (live <= handover_paths) {
+                    handover = bounce;
+                    paths_estimate = std::max<uint32_t>(live, 1);
                     probing = false;
                 }
             }
-            if (bounce >= tail_bounce) {
-                rp.tail_bounce = bounce;
-                HIP_TRY(timer.begin(stream, EventTimer::TAIL));
-                HIP_TRY(launch_tail(scene, tail, P, rp, bounce, tail_estimate, stream));
+            if (bounce >= handover) {
+                rp.handover = bounce;
+                HIP_TRY(timer.begin(stream, EventTimer::PATHS));
+                HIP_TRY(launch_paths(scene, paths_plan, P, rp, bounce, std::min(paths_estimate, rp.n_paths), stream));
                 HIP_TRY(timer.end(stream));
-                ++launches_tail;
+                ++launches_paths;
                 break;
             }
             HIP_TRY(timer.begin(stream, EventTimer::EXTEND));
@@ -822,7 +853,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         std::memset(stats, 0, sizeof *stats);
         stats->samples = (uint64_t)n_pixels * n_samples_total;
         stats->segments = segments[0];
-        stats->segments_tail = segments[1];
+        stats->segments_paths = segments[1];
         stats->passes = passes;
         stats->launches_extend = launches_extend;
         stats->launches_shade = launches_shade;
@@ -831,9 +862,9 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         stats->ms_bin = timer.ms[EventTimer::BIN];
         stats->ms_shade = timer.ms[EventTimer::SHADE];
         stats->ms_accumulate = timer.ms[EventTimer::ACCUMULATE];
-        stats->ms_tail = timer.ms[EventTimer::TAIL];
-        stats->launches_tail = launches_tail;
-        stats->tail_bounce = tail_bounce;
+        stats->ms_paths = timer.ms[EventTimer::PATHS];
+        stats->launches_paths = launches_paths;
+        stats->handover_bounce = handover;
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     }
     return MIRT_OK;

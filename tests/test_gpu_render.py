@@ -103,28 +103,33 @@ def test_tile_split_and_sample_split_reassemble_the_image(worlds):
 
 
 @pytest.mark.parametrize("name", ["C1", "C3", "C4", "C5"])
-def test_tail_kernel_does_not_change_the_image(name, worlds):
-    """Where the launches per bounce hand over to the one-kernel tail is scheduling only:
-    never, at bounce 1, 2 or 7, or chosen automatically, the bytes and the number of
-    closest-hit queries are the same."""
+def test_handover_to_the_path_kernel_does_not_change_the_image(name, worlds):
+    """Whether a path's bounces run as launches per bounce over queues or inside the path
+    kernel is scheduling only: handing over never, at bounce 0 (the default), 1, 2 or 7, or
+    at a probed bounce, the bytes and the number of closest-hit queries are the same."""
     cfg = configs.ALL[name]
     w, h, spp = FRAMES[name]
     world = worlds(name)
     cam = cfg.camera(w, h)
     scene = api.Scene(world)
     try:
-        never, st_never = api.render_world(cfg.background, scene, cam, w, h, spp, tail=(-1, 0), return_stats=True)
-        assert st_never["launches_tail"] == 0 and st_never["segments_tail"] == 0
-        for tail in ((1, 0), (2, 0), (7, 0), (0, 0), (0, 1 << 30), (0, 200)):
-            img, st = api.render_world(cfg.background, scene, cam, w, h, spp, tail=tail, return_stats=True,
+        never, st_never = api.render_world(cfg.background, scene, cam, w, h, spp, handover=(abi.HANDOVER_NEVER, 0),
+                                           return_stats=True)
+        assert st_never["launches_paths"] == 0 and st_never["segments_paths"] == 0
+        assert st_never["handover_bounce"] == api.MAX_DEPTH
+        for handover in ((0, 0), (1, 0), (2, 0), (7, 0), (abi.HANDOVER_PROBE, 0), (abi.HANDOVER_PROBE, 1 << 30),
+                         (abi.HANDOVER_PROBE, 200)):
+            img, st = api.render_world(cfg.background, scene, cam, w, h, spp, handover=handover, return_stats=True,
                                        paths_per_pass=w * h * 2)
-            assert np.array_equal(img, never), (name, tail)
-            assert st["segments"] == st_never["segments"], (name, tail)
-            if tail[0] > 0:
-                assert st["tail_bounce"] == tail[0] and st["launches_tail"] == st["passes"]
-                assert 0 < st["segments_tail"] < st["segments"]
-        # the automatic choice with a threshold nothing stays under: a launch per bounce throughout
-        _, st = api.render_world(cfg.background, scene, cam, w, h, spp, tail=(0, 1), return_stats=True)
+            assert np.array_equal(img, never), (name, handover)
+            assert st["segments"] == st_never["segments"], (name, handover)
+            if handover[0] >= 0:
+                assert st["handover_bounce"] == handover[0] and st["launches_paths"] == st["passes"]
+                assert 0 < st["segments_paths"] <= st["segments"]
+            if handover[0] == 0:
+                assert st["segments_paths"] == st["segments"] and st["launches_extend"] == 0
+        # a probe threshold nothing stays under: a launch per bounce throughout
+        _, st = api.render_world(cfg.background, scene, cam, w, h, spp, handover=(abi.HANDOVER_PROBE, 1), return_stats=True)
         assert st["segments"] == st_never["segments"]
     finally:
         scene.close()
