@@ -100,7 +100,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from ray_tracer_amd import api, configs
+    from ray_tracer_amd import api, configs, distributed
 
     if not torch.cuda.is_available() or api.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: no HIP device visible")
@@ -135,25 +135,15 @@ def main():
         if args.split == "tile" or world_size == 1:
             # rows interleaved over ranks: tile = one row, rank r owns rows r, r + N, ...
             _, st = api.render_world(cfg.background, scene, cam, W, H, spp, paths_per_pass=args.paths_per_pass,
-                                     profile=profile, out=out, return_stats=True, tiles=(W, world_size, rank),
-                                     handover=(args.handover, 0))
-            if world_size > 1:
-                mine = torch.from_numpy(np.ascontiguousarray(out[rank::world_size]))
-                if rank == 0:
-                    parts = [torch.empty_like(torch.from_numpy(np.ascontiguousarray(out[r::world_size])))
-                             for r in range(world_size)]
-                    dist.gather(mine, parts, dst=0, group=gloo)
-                    for r in range(1, world_size):
-                        out[r::world_size] = parts[r].numpy()
-                else:
-                    dist.gather(mine, None, dst=0, group=gloo)
+                                     profile=profile, out=out, return_stats=True,
+                                     tiles=distributed.row_tiles(W, world_size, rank), handover=(args.handover, 0))
+            distributed.gather_rows(out, rank, world_size, group=gloo)
         else:
             accum.zero_()
-            lo = rank * spp // world_size
-            hi = (rank + 1) * spp // world_size
+            lo, hi = distributed.sample_range(spp, rank, world_size)
             st = api.render_accumulate(scene, cam, cfg.background, W, H, spp, accum.data_ptr(), sample_range=(lo, hi),
                                        paths_per_pass=args.paths_per_pass, profile=profile, handover=(args.handover, 0))
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+            distributed.reduce_accum(accum)  # RCCL over xGMI
             if rank == 0:
                 api.resolve(accum.data_ptr(), W, H, spp, out=out)
         return st

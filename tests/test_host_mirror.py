@@ -1,0 +1,190 @@
+"""The C++ host mirror of the reference's set-up code (ray_tracer_amd/host: BVH build,
+bounding boxes, camera, Perlin tables, world constructors, config reader, PPM writer)
+against the oracle's independent restatement and against the reference's documented
+behaviour.  CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scene_util as su
+from ray_tracer_amd import _abi as abi
+from ray_tracer_amd import api, configs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "ray_tracer_amd", "host", "mirt_render")
+
+
+def _raw(struct_array):
+    return bytes(memoryview(struct_array).cast("B"))
+
+
+def _random_shapes(rng, n):
+    out = []
+    for i in range(n):
+        k = i % 6
+        c = rng.uniform(-20, 20, 3)
+        if k == 0:
+            out.append(su.sphere(*c, rng.uniform(0.1, 2.0)))
+        elif k in (1, 2, 3):
+            a0, b0 = rng.uniform(-20, 20, 2)
+            out.append(su.shape(k, 0, a0, a0 + rng.uniform(0.5, 5), b0, b0 + rng.uniform(0.5, 5), rng.uniform(-20, 20)))
+        elif k == 4:
+            out.append(su.shape(abi.SHAPE_CUBE, 0, *c, *(c + rng.uniform(0.5, 3, 3))))
+        else:
+            out.append(su.moving_sphere(c, c + rng.uniform(-1, 1, 3), rng.uniform(0.1, 1.0), 0.0, 1.0))
+    return out
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (3, 3), (7, 4), (64, 5), (257, 6)])
+def test_bvh_build_equals_the_oracles(n, seed):
+    rng = np.random.default_rng(seed)
+    shapes = _random_shapes(rng, n)
+    a = (abi.Shape * n)(*shapes)
+    b = (abi.Shape * n)(*shapes)
+    na = (abi.BvhMember * (2 * n - 1))()
+    nb = (abi.BvhMember * (2 * n - 1))()
+    assert abi.libhost().mirt_host_bvh_build(a, n, 0.0, 1.0, 100 + seed, na) == 2 * n - 1
+    assert oracle_lib.lib().oracle_bvh_build(b, n, 0.0, 1.0, 100 + seed, nb) == 2 * n - 1
+    assert _raw(a) == _raw(b)      # the same sorted shape order
+    assert _raw(na) == _raw(nb)    # the same members, bit for bit
+
+
+def test_shape_bbox_camera_and_perlin_equal_the_oracles():
+    rng = np.random.default_rng(11)
+    H, O = abi.libhost(), oracle_lib.lib()
+    d3 = C.c_double * 3
+    for s in _random_shapes(rng, 60) + [su.sphere(1, 2, 3, -0.5)]:
+        lo_h, hi_h, lo_o, hi_o = d3(), d3(), d3(), d3()
+        assert H.mirt_host_shape_bbox(C.byref(s), 0.0, 1.0, lo_h, hi_h) == 0
+        O.oracle_shape_bbox(C.byref(s), 0.0, 1.0, lo_o, hi_o)
+        assert list(lo_h) == list(lo_o) and list(hi_h) == list(hi_o)
+    for _ in range(20):
+        args = (d3(*rng.uniform(-10, 10, 3)), d3(*rng.uniform(-10, 10, 3)), d3(0, 1, 0), rng.uniform(10, 90),
+                rng.uniform(0.5, 2.5), rng.uniform(0, 0.5), 10.0, 0.0, 1.0)
+        ch, co = abi.Camera(), abi.Camera()
+        assert H.mirt_host_camera_new(*args, C.byref(ch)) == 0
+        O.oracle_camera_new(*args, C.byref(co))
+        assert bytes(ch) == bytes(co)
+    for seed in (0, 1, 0xDEADBEEF):
+        ph, po = abi.Perlin(), abi.Perlin()
+        assert H.mirt_host_perlin_new(seed, C.byref(ph)) == 0
+        O.oracle_perlin_new(seed, C.byref(po))
+        assert bytes(ph) == bytes(po)
+
+
+def test_camera_of_the_reference_defaults():
+    # Camera::new (camera.rs:21-63) for look_from (0,0,1) -> look_at (0,0,0), fov 90, aspect 2, no lens
+    cam = api.Camera.new((0, 0, 1), (0, 0, 0), (0, 1, 0), 90.0, 2.0, 0.0, 1.0, 0.0, 1.0).c
+    assert list(cam.origin) == [0.0, 0.0, 1.0]
+    assert list(cam.w) == [0.0, 0.0, 1.0] and list(cam.u) == [1.0, 0.0, 0.0] and list(cam.v) == [0.0, 1.0, 0.0]
+    assert cam.lens_radius == 0.0
+    # half_height = tan(45 deg) ~ 1, half_width ~ 2
+    assert list(cam.horizontal) == pytest.approx([4.0, 0.0, 0.0], rel=1e-15)
+    assert list(cam.vertical) == pytest.approx([0.0, 2.0, 0.0], rel=1e-15)
+    assert list(cam.lower_left_corner) == pytest.approx([-2.0, -1.0, 0.0], rel=1e-15, abs=1e-15)
+
+
+@pytest.mark.parametrize("scene", ["Basic", "Dynamic", "Checker", "Perlin", "Earth", "SimpleLight", "CornellBox",
+                                   "Textured", "NextWeek"])
+def test_every_world_generates_and_is_a_valid_bvh(scene):
+    earth = configs.load_earth() if scene in ("Earth", "Textured", "NextWeek") else None
+    w = api.World.generate(scene, 10, 42, 0.0, 1.0, earth_rgb=earth)
+    d = w.desc.contents
+    assert d.n_shapes >= 1 and d.n_nodes == 2 * d.n_shapes - 1
+    nodes = [d.nodes[i] for i in range(d.n_nodes)]
+    assert sorted(m.shape for m in nodes if m.is_leaf) == list(range(d.n_shapes))
+    for i, m in enumerate(nodes):
+        if not m.is_leaf:
+            assert m.left < i and m.right < i
+    for i in range(d.n_shapes):
+        assert d.shapes[i].material < d.n_materials
+    # the same seed gives the same world, another seed another one (where the scene draws at all)
+    w2 = api.World.generate(scene, 10, 42, 0.0, 1.0, earth_rgb=earth)
+    same = bytes(memoryview((abi.Shape * d.n_shapes).from_address(C.addressof(d.shapes.contents))).cast("B"))
+    d2 = w2.desc.contents
+    assert same == bytes(memoryview((abi.Shape * d2.n_shapes).from_address(C.addressof(d2.shapes.contents))).cast("B"))
+    w.close()
+    w2.close()
+
+
+def test_benchmark_worlds_have_the_documented_sizes():
+    c2 = configs.C2.world()
+    assert (c2.n_shapes, c2.n_nodes) == (488, 975)  # 484 random spheres + ground + three big ones
+    c5 = configs.C5.world()
+    assert c5.n_shapes == 3507
+    with pytest.raises(api.MirtError):
+        api.World.generate("NoSuchScene")
+
+
+def test_ppm_create_writes_the_reference_format(tmp_path):
+    # ppm.rs:6-27: "P3\n<w> <h>\n255\n" then "r g b\n" per pixel
+    px = np.array([[[255, 0, 1], [2, 3, 4]], [[5, 6, 7], [8, 9, 10]], [[0, 0, 0], [100, 200, 50]]], dtype=np.uint8)
+    path = tmp_path / "out.ppm"
+    rc = abi.libhost().mirt_host_ppm_create(str(path).encode(), 2, 3, px.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert rc == 0
+    assert path.read_text() == "P3\n2 3\n255\n255 0 1\n2 3 4\n5 6 7\n8 9 10\n0 0 0\n100 200 50\n"
+    assert abi.libhost().mirt_host_ppm_create(b"/nonexistent-dir/x.ppm", 2, 3, px.ctypes.data_as(C.POINTER(C.c_uint8))) != 0
+
+
+# ------------------------------------------------------------------ the command line
+GOOD_TOML = """
+[output]
+type = "ppm"
+output_path = "{out}"
+
+[renderer]
+screen_width = 16
+screen_height = 8
+antialias_iterations = 2
+render_parallel = true
+use_bounding_volume = true
+
+[world]
+scene = "Basic"
+max_objects = 5
+
+[camera]
+aperture = 0.0
+fov = 40.0
+look_from = {{ x = 3.0, y = 3.0, z = 2.0 }}
+look_at = {{ x = 0.0, y = 0.0, z = -1.0 }}
+"""
+
+
+def _run_cli(tmp_path, text):
+    cfg = tmp_path / "tracer.toml"
+    cfg.write_text(text)
+    env = dict(os.environ, TRACER_CONFIG_PATH=str(cfg), TRACER_SEED="7", TRACER_BACKGROUND="0.5,0.7,1.0")
+    return subprocess.run([CLI], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+
+
+def test_cli_rejects_what_the_reference_panics_on(tmp_path):
+    # config.rs:210-217: unreadable or malformed config, missing section, unknown scene -> panic (exit 101)
+    r = _run_cli(tmp_path, "this is not toml = = =")
+    assert r.returncode == 101 and "error" in r.stderr
+    no_world = GOOD_TOML.format(out=tmp_path / "o.ppm").replace('[world]\nscene = "Basic"\nmax_objects = 5\n', "")
+    r = _run_cli(tmp_path, no_world)
+    assert r.returncode == 101 and "world" in r.stderr
+    r = _run_cli(tmp_path, GOOD_TOML.format(out=tmp_path / "o.ppm").replace('"Basic"', '"Nope"'))
+    assert r.returncode == 101
+    env = dict(os.environ, TRACER_CONFIG_PATH=str(tmp_path / "missing.toml"))
+    r = subprocess.run([CLI], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 101
+
+
+def test_cli_renders_on_a_gpu_and_fails_loudly_without_one(tmp_path):
+    out = tmp_path / "o.ppm"
+    r = _run_cli(tmp_path, GOOD_TOML.format(out=out))
+    assert "Start world gen" in r.stdout and "Start tracing" in r.stdout  # main.rs:62-83 progress lines
+    if api.device_count() > 0:
+        assert r.returncode == 0, r.stderr
+        assert "End ppm creation" in r.stdout
+        assert out.read_text().startswith("P3\n16 8\n255\n") and len(out.read_text().splitlines()) == 3 + 16 * 8
+    else:
+        # no CPU fallback exists: the render call must fail, and say why
+        assert r.returncode != 0 and not out.exists()
+        assert "device" in r.stderr.lower() or "hip" in r.stderr.lower()
