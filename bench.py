@@ -220,6 +220,14 @@ def main():
                 "launches": launches,
                 "note": "not HBM-bound by design: see valu_f64 for the resource that limits it",
             }
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 runs of this
+            # same workload, committed under profiles/), scaled to this run's paths per launch
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_paths.json")
+            if args.config == "C2" and os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                result["roofline"]["traffic"] = pmc["hbm_bytes_per_path"] * samples / launches
+                result["roofline"]["traffic_source"] = "profiles/r01_pmc_k_paths.json (bytes per path x paths per launch)"
         elif profile and tot["ms_extend"] > 0:
             launches = tot["launches_extend"]
             avg_ms = tot["ms_extend"] / launches

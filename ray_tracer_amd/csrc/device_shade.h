@@ -223,14 +223,13 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, cons
         const uint32_t kind = t->kind;
         if (kind == MIRT_TEX_CONSTANT) return v3(t->color[0], t->color[1], t->color[2]);
         if (kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
-            // one sin() at a time: three inlined side by side cost ~100 more registers
-            double sines = 1.0;
-#pragma nounroll
-            for (int a = 0; a < 3; ++a) {
-                const double x = a == 0 ? h.p.x : (a == 1 ? h.p.y : h.p.z);
-                const double s = sin(10.0 * x);
-                sines = a == 0 ? s : sines * s;
-            }
+            // one sin() at a time: the scheduler would interleave three inlined side by side and
+            // hold ~100 more registers
+            double sines = sin(10.0 * h.p.x);
+            __builtin_amdgcn_sched_barrier(0);
+            sines = sines * sin(10.0 * h.p.y);
+            __builtin_amdgcn_sched_barrier(0);
+            sines = sines * sin(10.0 * h.p.z);
             tex = (sines < 0.0) ? t->odd : t->even;
             continue;
         }

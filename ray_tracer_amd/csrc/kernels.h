@@ -39,7 +39,8 @@ struct Paths {
     double *bx, *by, *bz;                        // product of attenuations so far
     double *hit_t;                               // closest hit of the current ray
     uint32_t* hit_ref;                           // shape index | side << 28, or HIT_MISS
-    double *rr, *rg, *rb;                        // radiance of the finished path
+    double4* radiance;                           // radiance of the finished path (x, y, z; w unused): one
+                                                 // 32-byte record per path, written once, by one lane
     uint64_t* stream;                            // sampler key of the path
     uint32_t* live[2];                           // live queues (slot indices), ping-pong by bounce parity
     uint8_t* cls_q;                              // shade class of live entry i (queue order)
@@ -101,6 +102,15 @@ struct RenderParams {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+
+// Three doubles into the path's 32-byte record: finished paths are scattered over the slots,
+// and a record keeps each path's result inside one 32-byte sector (three separate arrays
+// measured 13x the algorithmic bytes at the memory side).
+__device__ __forceinline__ void store_radiance(const Paths& P, uint32_t slot, const V3& c) {
+    double* __restrict__ v = reinterpret_cast<double*>(P.radiance + slot);
+    *reinterpret_cast<double2*>(v) = make_double2(c.x, c.y);
+    v[2] = c.z;
+}
 
 // ---------------------------------------------------------------- closest hit
 // MODE_LIST and MODE_REFERENCE: one ray per lane from start to finish (simple forms,
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
                 P.dx[slot] = s.direction.x; P.dy[slot] = s.direction.y; P.dz[slot] = s.direction.z;
                 P.bx[slot] = s.beta.x; P.by[slot] = s.beta.y; P.bz[slot] = s.beta.z;
             } else {
-                P.rr[slot] = s.radiance.x; P.rg[slot] = s.radiance.y; P.rb[slot] = s.radiance.z;
+                store_radiance(P, slot, s.radiance);
             }
         }
         // ---- append survivors: ballot per wave, one atomic per block step
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
                     ++bounce;
                     walk.begin(sc, r, rp.t_min, rp.t_max);
                 } else {
-                    P.rr[slot] = s.radiance.x; P.rg[slot] = s.radiance.y; P.rb[slot] = s.radiance.z;
+                    store_radiance(P, slot, s.radiance);
                     have = false;
                     walk.reset();
                 }
@@ -681,9 +691,10 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, 
         double r = accum[3 * idx + 0], g = accum[3 * idx + 1], b = accum[3 * idx + 2];
         for (uint32_t s = 0; s < rp.n_samples; ++s) {
             const size_t slot = (size_t)s * rp.n_pixels + k;
-            r += P.rr[slot];
-            g += P.rg[slot];
-            b += P.rb[slot];
+            const double* __restrict__ v = reinterpret_cast<const double*>(P.radiance + slot);
+            r += v[0];
+            g += v[1];
+            b += v[2];
         }
         accum[3 * idx + 0] = r;
         accum[3 * idx + 1] = g;

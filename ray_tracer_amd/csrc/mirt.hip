@@ -725,9 +725,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     Paths P;
     std::memset(&P, 0, sizeof P);
     P.capacity = capacity;
-    HIP_TRY(arena.alloc(&P.rr, (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.rg, (size_t)capacity));
-    HIP_TRY(arena.alloc(&P.rb, (size_t)capacity));
+    HIP_TRY(arena.alloc(&P.radiance, (size_t)capacity));
     if (!from_start) {
         double** f64_arrays[] = {&P.ox, &P.oy, &P.oz, &P.dx, &P.dy, &P.dz, &P.time, &P.bx, &P.by, &P.bz, &P.hit_t};
         for (double** a : f64_arrays) HIP_TRY(arena.alloc(a, (size_t)capacity));

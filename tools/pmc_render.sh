@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collects SQ / TCC counters on a short C2 render, one rocprofv3 run per counter group
 # (counters are not split over passes automatically).
-# usage: tools/pmc_extend.sh <outdir> [groups...]   groups: sq1 sq2 tcc1 fetch write (default: sq1 sq2)
+# usage: [SPP=16] [BENCH_ARGS=...] tools/pmc_render.sh <outdir> [groups...]   groups: sq1 sq2 tcc1 fetch write (default: sq1 sq2)
 OUT=$1; shift
 GROUPS_WANTED=${@:-sq1 sq2}
 export TMPDIR=/tmp
 mkdir -p $OUT
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python3 bench.py --spp 16 --steps 1 --warmup 0 --cpu-seconds 0 --no-profile > $OUT/$name.log 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python3 bench.py --spp ${SPP:-16} --steps 1 --warmup 0 --cpu-seconds 0 --no-profile ${BENCH_ARGS:-} > $OUT/$name.log 2>&1 || exit 1
 }
 for g in $GROUPS_WANTED; do
   case $g in
