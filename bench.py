@@ -31,8 +31,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# bytes the path kernel moves per sample: the finished path's radiance (3 f64) out
-PATHS_BYTES_PER_SAMPLE = 24
 # bytes one closest-hit query moves through the ray queues in HBM: ray in (7 f64) + hit record out (t, ref)
 EXTEND_BYTES_PER_SEGMENT = 56 + 16
 # bytes per path segment over the whole extend + bin + shade step, and per sample for the accumulator
@@ -205,7 +203,10 @@ def main():
         if profile and dominant == "ms_paths" and tot["ms_paths"] > 0:
             launches = tot["launches_paths"]
             avg_ms = tot["ms_paths"] / launches
-            achieved = samples * PATHS_BYTES_PER_SAMPLE / launches / (avg_ms * 1e-3) / 1e9
+            # the algorithmic bytes of the path, per segment and per sample, whatever the kernel keeps in
+            # registers instead of moving: the same figure prices the per-bounce pipeline below
+            bytes_per_launch = (tot["segments_paths"] * PIPELINE_BYTES_PER_SEGMENT + samples * PIPELINE_BYTES_PER_SAMPLE) / launches
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             result["roofline"] = {
                 "bound": "hbm",
                 "kernel": "k_paths (whole paths, one per lane: camera ray, closest hit, shade, next bounce, in registers)",
@@ -214,11 +215,14 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "bytes_per_unit": PATHS_BYTES_PER_SAMPLE,
-                "units_per_launch": samples / launches,
+                "bytes_per_unit": {"segment": PIPELINE_BYTES_PER_SEGMENT, "sample": PIPELINE_BYTES_PER_SAMPLE},
+                "units_per_launch": {"segments": tot["segments_paths"] / launches, "samples": samples / launches},
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
-                "note": "not HBM-bound by design: see valu_f64 for the resource that limits it",
+                "note": "algorithmic bytes = what a queue-per-bounce pipeline moves through HBM for these segments (ray 56 + hit "
+                        "16 + path state 88 in, 88 out + two queue indices 8 = 272 B per segment, 24 B per sample); this kernel keeps "
+                        "all of it in registers, so `traffic` (measured) is far below it and the kernel is bound by the f64 vector "
+                        "ALU (valu_f64), not by HBM",
             }
             # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 runs of this
             # same workload, committed under profiles/), scaled to this run's paths per launch
