@@ -1,34 +1,29 @@
-// device_traverse.h -- the closest-hit engine of the extend kernel: persistent
-// waves that walk the two-boxes-per-node tree of accel_build.h in "while-while"
-// form, 64 rays per wave, refilling finished lanes from the ray queue.
+// device_traverse.h -- closest-hit queries against the two-boxes-per-node tree of
+// accel_build.h: the walk of one ray cut into steps (RayWalk), and two drivers that run 64
+// walks per wave -- traverse_persistent (a queue of rays; the extend kernel and
+// mirt_intersect) and the path kernel's own loop in kernels.h.
 //
 // Why this shape (measured on MI355X, RTIOW scene):
-//  * The first kernel ran one ray per lane to completion.  Only 31 % of the lanes
-//    were active in the average vector instruction: rays of one wave need very
-//    different numbers of node visits, and the sphere tests ran inside the node loop
-//    for the few lanes that had reached a leaf.  The vector ALU was busy 23 % of the
-//    time; the rest went to 128-byte node fetches that touch 64 different L1 lines
-//    per wave instruction.
-//  * With nodes in LDS and refill, waves still sat in s_waitcnt 58 % of their cycles:
-//    every refill stalled the whole wave on a fresh gather of rays from HBM, and every
-//    leaf phase on shape parameters fetched from L2.
-// Hence:
-//  * inner loop = node visits only; a lane that meets leaves parks them in two
-//    registers and leaves the loop; leaf tests run after it for all parked lanes;
-//  * a lane whose ray is finished takes its NEXT ray from registers: the ray was
-//    requested one refill earlier and has arrived while the wave kept traversing;
-//  * when they fit, the tree's nodes (104 B each) and the shapes' parameters (80 B
-//    each) are staged in LDS once per workgroup, so that the traversal loop touches
-//    global memory only to prefetch rays and to store results;
-//  * the slab test reads the near/far bound of each axis by address (8-byte LDS
-//    read at base + 8 * sign) instead of loading both bounds and selecting;
-//  * the per-lane stack lives in LDS as [level][thread] and holds inner-node
-//    indices only (16-bit when the tree has < 65536 nodes).
+//  * One ray per lane run to completion left 31 % of the lanes active in the average vector
+//    instruction: rays of one wave need very different numbers of node visits, and shape tests
+//    ran inside the node loop for the few lanes that had reached a leaf.  Hence steps: a lane
+//    that meets leaves parks their shapes in registers; the wave runs node visits for the
+//    lanes that want one and shape tests for the lanes that have parked some, whichever more
+//    lanes wait for, and leaves a loop early when few lanes still want it.
+//  * 128-byte node fetches from 64 different addresses per wave instruction kept waves in
+//    s_waitcnt most of their cycles.  When they fit, the tree's nodes (104 B each) and the
+//    shapes' parameters (80 B each) are staged in LDS once per workgroup.
+//  * The slab test reads the near / far bound of each axis by address (8-byte read at
+//    base + 8 * sign) instead of loading both bounds and selecting.
+//  * The per-lane stack lives in LDS as [level][thread] and holds inner-node indices only
+//    (16-bit when the tree has < 65536 nodes).
+//  * traverse_persistent: waves pull chunks of rays from a global counter and request the
+//    next ray of a lane while the current one is traced.
 //
-// Decisions are the reference's (device_intersect.h, accel_build.h): exact slab test
-// with the caller's (t_min, t_max) at every box that admits something, shapes tested
-// with the caller's (t_min, t_max), smallest t wins and equal t goes to the larger
-// shape index, extra distance prune with a relative margin.
+// Decisions are the reference's (device_intersect.h, accel_build.h): exact slab test with
+// the caller's (t_min, t_max) at every box that admits something, shapes tested with the
+// caller's (t_min, t_max), smallest t wins and equal t goes to the larger shape index, extra
+// distance prune with a relative margin.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -1,23 +1,31 @@
-// kernels.h -- the gfx950 kernels of the wavefront path tracer.
+// kernels.h -- the gfx950 kernels of the path tracer.
 //
-// renderer.rs's per-pixel loop (src/renderer.rs:64-115) is restructured into
-// passes.  One pass holds `n_paths` camera paths = B samples of every pixel of
-// the range, one path per slot of a structure-of-arrays state in HBM, and runs
+// renderer.rs's per-pixel loop (src/renderer.rs:64-115) is restructured into passes.  One
+// pass holds `n_paths` camera paths = B samples of every pixel of the range, path `slot` =
+// sample (sample_base + slot / n_pixels) of pixel (slot % n_pixels), and runs either
 //
-//   raygen                                   renderer.rs:74-82 + camera.rs:65-76
-//   for bounce in 0 .. max_depth:
+//   paths        every path from its camera ray to its end, one lane per path, all in
+//                registers (k_paths)               renderer.rs:74-82, 92-115
+//
+// or, bounce by bounce over queues of live paths whose state lives in HBM,
+//
+//   raygen                                          renderer.rs:74-82 + camera.rs:65-76
+//   for bounce in 0 .. handover:
 //       extend   closest hit of every live path     renderer.rs:103 -> bvh.rs:37-80
 //       bin      sort the live queue by shade class (material/texture kind)
 //       shade    emit / scatter / terminate, append survivors to the next live
 //                queue                              renderer.rs:104-114 -> material.rs
+//   paths        from bounce `handover` on (unless handover = max_depth)
+//
+// then
+//
 //   accumulate   pixel += sample radiance, in sample order   renderer.rs:83
 //
 // and after the last pass `resolve` does renderer.rs:85-89 and the u8 cast.
 //
-// Queues hold slot indices; counts live in device memory (`counters`), so the
-// host enqueues a whole pass without reading anything back.  Kernels are
-// launched with a fixed grid and stride over the work; a kernel whose queue is
-// empty returns at once.
+// Queues hold slot indices; counts live in device memory (`counters`), so the host enqueues
+// a whole pass without reading anything back.  Kernels are launched with a fixed grid and
+// stride (or pull) over the work; a kernel whose queue is empty returns at once.
 #pragma once
 
 #include <hip/hip_runtime.h>
