@@ -17,12 +17,19 @@
 
 namespace mirt {
 
-// Draws of one stage of one camera path (include/mirt_rng.h).
+// Draws of one stage of one camera path (include/mirt_rng.h): draw k of stage s is
+// mix64(stream + GOLDEN * ((s << 32 | k) + 1)).  The argument is kept as a running sum, so a
+// draw costs the two 64-bit multiplications of the mixer and an addition.
 struct PathRng {
     uint64_t stream;
-    uint32_t stage;
-    uint32_t k;
-    __device__ __forceinline__ double random_double() { return mirt_rng_double(stream, stage, k++); }  // util.rs:8-10
+    uint64_t arg;  // stream + GOLDEN * ((stage << 32 | k) + 1) for the next draw
+    __device__ __forceinline__ PathRng(uint64_t stream_, uint32_t stage, uint32_t k)
+        : stream(stream_), arg(stream_ + MIRT_GOLDEN * ((((uint64_t)stage << 32) | (uint64_t)k) + 1u)) {}
+    __device__ __forceinline__ double random_double() {  // util.rs:8-10
+        const double x = mirt_bits_to_double(mirt_mix64(arg));
+        arg += MIRT_GOLDEN;
+        return x;
+    }
 };
 
 // camera.rs:78-88

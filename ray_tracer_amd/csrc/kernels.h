@@ -600,10 +600,27 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
     walk.reset();
     const int stay = (int)(tuning & 0xFFu), shade_at = (int)((tuning >> 8) & 0xFFu);
     const int refill_at = (int)((tuning >> 16) & 0xFFu);
+#ifdef MIRT_PATHS_STATS
+    // development build: wave clocks and lane counts per piece of code, summed into P.segments[2..]
+    enum { PS_REFILL, PS_SHADE, PS_NODE, PS_LEAF, PS_N };
+    unsigned long long ps_clk[PS_N] = {}, ps_trips[PS_N] = {}, ps_lanes[PS_N] = {};
+    const unsigned long long ps_begin = __builtin_amdgcn_s_memtime();
+#define PS_START() const unsigned long long ps_t0 = __builtin_amdgcn_s_memtime()
+#define PS_STOP(k, lanes)                                                   \
+    do {                                                                    \
+        ps_clk[k] += __builtin_amdgcn_s_memtime() - ps_t0;                  \
+        ps_trips[k] += 1;                                                   \
+        ps_lanes[k] += (lanes);                                             \
+    } while (0)
+#else
+#define PS_START() do {} while (0)
+#define PS_STOP(k, lanes) do {} while (0)
+#endif
     for (;;) {
         const unsigned long long need = __ballot(!have);
         // one queue access (a global atomic) serves many lanes: wait until enough are empty
         if (!exhausted && (__popcll(need) >= refill_at || need == ~0ull)) {
+            PS_START();
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(work, (uint32_t)__popcll(need));
             base = __builtin_amdgcn_readfirstlane(base);
@@ -631,6 +648,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
                 walk.begin(sc, r, rp.t_min, rp.t_max);
             }
             exhausted = base + (uint32_t)__popcll(need) >= n;
+            PS_STOP(PS_REFILL, __popcll(need));
         }
         const int n_node = __popcll(__ballot(have && walk.wants_node()));
         const int n_leaf = __popcll(__ballot(have && walk.wants_leaf()));
@@ -640,6 +658,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
             continue;              // every lane is empty: the next trip refills
         }
         if (n_shade >= shade_at || n_node + n_leaf == 0) {
+            PS_START();
             if (have && walk.finished()) {
                 if (bounce != bounce0) ++extra_segments;
                 const HitRec h = walk.best;
@@ -664,19 +683,26 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
                     walk.reset();
                 }
             }
+            PS_STOP(PS_SHADE, n_shade);
             continue;
         }
         const int enough = max(1, ((n_node + n_leaf) * stay) >> 3);
         if (n_leaf > n_node) {
             int n_now;
+            n_now = n_leaf;
             do {
+                PS_START();
                 if (have && walk.wants_leaf()) walk.leaf_step(sc, lds, rp.t_min, rp.t_max);
+                PS_STOP(PS_LEAF, n_now);
                 n_now = __popcll(__ballot(have && walk.wants_leaf()));
             } while (n_now >= enough);
         } else {
             int n_now;
+            n_now = n_node;
             do {
+                PS_START();
                 if (have && walk.wants_node()) walk.node_step(sc, lds, stack, tid, rp.t_min, rp.t_max);
+                PS_STOP(PS_NODE, n_now);
                 n_now = __popcll(__ballot(have && walk.wants_node()));
             } while (n_now >= enough);
         }
@@ -687,6 +713,18 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
         atomicAdd(P.segments + 0, (unsigned long long)extra_segments);
         atomicAdd(P.segments + 1, (unsigned long long)extra_segments);
     }
+#ifdef MIRT_PATHS_STATS
+    if (lane == 0) {
+        for (int k = 0; k < PS_N; ++k) {
+            atomicAdd(P.segments + 2 + 3 * k, ps_clk[k]);
+            atomicAdd(P.segments + 3 + 3 * k, ps_trips[k]);
+            atomicAdd(P.segments + 4 + 3 * k, ps_lanes[k]);
+        }
+        atomicAdd(P.segments + 2 + 3 * PS_N, (unsigned long long)(__builtin_amdgcn_s_memtime() - ps_begin));
+    }
+#endif
+#undef PS_START
+#undef PS_STOP
 }
 
 // ------------------------------------------------------------------ accumulate

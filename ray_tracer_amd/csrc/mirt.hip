@@ -738,9 +738,10 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     }
     const Counters C{max_depth};
     HIP_TRY(arena.alloc(&P.counters, (size_t)C.total()));
-    HIP_TRY(arena.alloc(&P.segments, (size_t)2));
+    constexpr size_t N_SEGMENT_WORDS = 2 + 16;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
+    HIP_TRY(arena.alloc(&P.segments, N_SEGMENT_WORDS));
     hipStream_t stream = 0;
-    HIP_TRY(hipMemsetAsync(P.segments, 0, 2 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(P.segments, 0, N_SEGMENT_WORDS * sizeof(unsigned long long), stream));
 
     RenderParams rp;
     std::memset(&rp, 0, sizeof rp);
@@ -842,10 +843,24 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         ++passes;
         probing = false;  // paths that never thin out: stay with a launch per bounce
     }
-    unsigned long long segments[2] = {0, 0};
+    unsigned long long segments[N_SEGMENT_WORDS] = {0};
     HIP_TRY(hipMemcpyAsync(segments, P.segments, sizeof segments, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
+#ifdef MIRT_PATHS_STATS
+    {
+        const char* names[4] = {"refill", "shade", "node", "leaf"};
+        const double total = (double)segments[2 + 12];
+        double sum = 0;
+        for (int k = 0; k < 4; ++k) {
+            const double clk = (double)segments[2 + 3 * k], trips = (double)segments[3 + 3 * k], lanes = (double)segments[4 + 3 * k];
+            sum += clk;
+            std::fprintf(stderr, "[k_paths] %-6s %5.1f %% of wave clocks, %10.0f trips, %7.0f clocks per trip, %4.1f lanes per trip\n",
+                         names[k], 100.0 * clk / total, trips, trips ? clk / trips : 0.0, trips ? lanes / trips : 0.0);
+        }
+        std::fprintf(stderr, "[k_paths] other  %5.1f %%\n", 100.0 * (total - sum) / total);
+    }
+#endif
 
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
