@@ -414,17 +414,24 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
         return out;
     }
     if (last) return out;
+    // Lanes of one wave may hold hits of different classes (path kernel): what several classes
+    // need is computed ONCE for all of them before the class branches -- the rejection loop of
+    // random_in_unit_sphere (first draws of the stage for lambertian and metal alike) and the
+    // unit direction (metal, dielectric) -- instead of once per class present in the wave.
     PathRng rng{stream, bounce + 1u, 0u};
+    const bool is_lambertian = cls != SHADE_METAL && cls != SHADE_DIELECTRIC;
+    V3 in_sphere = v3(0.0, 0.0, 0.0), unit_direction = v3(0.0, 0.0, 0.0);
+    if (cls != SHADE_DIELECTRIC) in_sphere = random_in_unit_sphere(rng);
+    if (!is_lambertian) unit_direction = unit(r.d);
     V3 dir, attenuation;
     bool scattered = true;
     if (cls == SHADE_METAL) {  // material.rs:74-91
-        const V3 reflected = reflect(unit(r.d), h.normal);
-        dir = reflected + m->param * random_in_unit_sphere(rng);
+        const V3 reflected = reflect(unit_direction, h.normal);
+        dir = reflected + m->param * in_sphere;
         scattered = dot(dir, h.normal) > 0.0;
         attenuation = v3(m->albedo[0], m->albedo[1], m->albedo[2]);
     } else if (cls == SHADE_DIELECTRIC) {  // material.rs:104-131
         const double refraction_ratio = h.front_facing ? 1.0 / m->param : m->param;
-        const V3 unit_direction = unit(r.d);
         const double cos_theta = fmin(dot(-unit_direction, h.normal), 1.0);
         const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
         const bool cannot_refract = refraction_ratio * sin_theta > 1.0;
@@ -435,7 +442,7 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
         }
         attenuation = v3(1.0, 1.0, 1.0);
     } else {  // the lambertian classes, material.rs:51-59
-        const V3 target = h.p + h.normal + random_in_unit_sphere(rng);
+        const V3 target = h.p + h.normal + in_sphere;
         dir = target - h.p;
         attenuation = texture_value(sc, m->texture, h, lds_tables, n_staged);
     }
