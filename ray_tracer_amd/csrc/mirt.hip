@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -87,7 +88,52 @@ struct mirt_scene {
     bool has_noise = false;
     bool regrouped = false;     // fast tree = SAH over the reference's leaf groups (else: reference topology)
     int cu_count = 0;
+    // One block of device memory a render call left behind for the next one (the per-pass
+    // buffers: 2 GB at the default pass size); a call takes it if it is large enough and
+    // gives back the larger of what it holds and what is cached.  Guarded by ws_mutex:
+    // calls on one scene may run concurrently, each then works in a block of its own.
+    mutable std::mutex ws_mutex;
+    mutable void* ws_ptr = nullptr;
+    mutable size_t ws_bytes = 0;
 };
+
+namespace {
+struct Workspace {
+    const mirt_scene* scene = nullptr;
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipError_t take(const mirt_scene* sc, size_t want) {
+        scene = sc;
+        {
+            std::lock_guard<std::mutex> lock(sc->ws_mutex);
+            if (sc->ws_ptr && sc->ws_bytes >= want) {
+                ptr = sc->ws_ptr;
+                bytes = sc->ws_bytes;
+                sc->ws_ptr = nullptr;
+                sc->ws_bytes = 0;
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e == hipSuccess) bytes = want;
+        else ptr = nullptr;
+        return e;
+    }
+    ~Workspace() {
+        if (!ptr) return;
+        void* drop = ptr;
+        {
+            std::lock_guard<std::mutex> lock(scene->ws_mutex);
+            if (bytes > scene->ws_bytes) {
+                drop = scene->ws_ptr;
+                scene->ws_ptr = ptr;
+                scene->ws_bytes = bytes;
+            }
+        }
+        if (drop) (void)hipFree(drop);
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -319,6 +365,7 @@ void mirt_scene_destroy(mirt_scene* scene) {
     (void)hipGetDevice(&prev);
     if (prev != scene->device) (void)hipSetDevice(scene->device);
     for (void* p : scene->allocations) (void)hipFree(p);
+    if (scene->ws_ptr) (void)hipFree(scene->ws_ptr);
     if (prev >= 0 && prev != scene->device) (void)hipSetDevice(prev);
     delete scene;
 }
@@ -720,12 +767,23 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     if (capacity64 > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "pass of %llu paths is too large", (unsigned long long)capacity64);
     const uint32_t capacity = (uint32_t)capacity64;
 
-    // ---- per-pass state
+    // ---- per-pass state: radiance records, counters and totals in one block (kept by the
+    // scene between calls), the queue pipeline's path state in arrays of this call
+    const Counters C{max_depth};
+    constexpr size_t N_SEGMENT_WORDS = 2 + 16;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
+    auto round256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t radiance_bytes = round256((size_t)capacity * sizeof(double4));
+    const size_t counters_bytes = round256((size_t)C.total() * sizeof(uint32_t));
+    const size_t segments_bytes = round256(N_SEGMENT_WORDS * sizeof(unsigned long long));
+    Workspace ws;  // declared before the stream work below ends: released after the final synchronise
+    HIP_TRY(ws.take(scene, radiance_bytes + counters_bytes + segments_bytes));
     DeviceArena arena;
     Paths P;
     std::memset(&P, 0, sizeof P);
     P.capacity = capacity;
-    HIP_TRY(arena.alloc(&P.radiance, (size_t)capacity));
+    P.radiance = reinterpret_cast<double4*>(ws.ptr);
+    P.counters = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.ptr) + radiance_bytes);
+    P.segments = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws.ptr) + radiance_bytes + counters_bytes);
     if (!from_start) {
         double** f64_arrays[] = {&P.ox, &P.oy, &P.oz, &P.dx, &P.dy, &P.dz, &P.time, &P.bx, &P.by, &P.bz, &P.hit_t};
         for (double** a : f64_arrays) HIP_TRY(arena.alloc(a, (size_t)capacity));
@@ -736,10 +794,6 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         HIP_TRY(arena.alloc(&P.cls_q, (size_t)capacity));
         HIP_TRY(arena.alloc(&P.cls_queue, (size_t)capacity * SHADE_NUM_CLASSES));
     }
-    const Counters C{max_depth};
-    HIP_TRY(arena.alloc(&P.counters, (size_t)C.total()));
-    constexpr size_t N_SEGMENT_WORDS = 2 + 16;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
-    HIP_TRY(arena.alloc(&P.segments, N_SEGMENT_WORDS));
     hipStream_t stream = 0;
     HIP_TRY(hipMemsetAsync(P.segments, 0, N_SEGMENT_WORDS * sizeof(unsigned long long), stream));
 

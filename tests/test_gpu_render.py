@@ -133,3 +133,29 @@ def test_handover_to_the_path_kernel_does_not_change_the_image(name, worlds):
         assert st["segments"] == st_never["segments"]
     finally:
         scene.close()
+
+
+def test_converged_images_agree_for_independent_random_streams(worlds, oracle):
+    """The gate for implementations whose random streams differ from the checker's (as the
+    reference's own would): the device render with one seed against the oracle with another,
+    at 256 spp.  Tolerance: per-channel RMSE (8-bit, after gamma) at most 1.5x the RMSE of two
+    oracle renders with different seeds (the noise floor at this sample count), and mean
+    luminance within 0.5 %."""
+    cfg = configs.C1
+    w, h, spp = 80, 45, 256
+    world = worlds("C1")
+    cam = cfg.camera(w, h)
+    gpu = api.render_world(cfg.background, world, cam, w, h, spp, seed=1111).astype(np.float64)
+    ref_a, _, _, _ = oracle.render(world.desc, cam, cfg.background, w, h, spp, seed=2222)
+    ref_b, _, _, _ = oracle.render(world.desc, cam, cfg.background, w, h, spp, seed=3333)
+    ref_a, ref_b = ref_a.astype(np.float64), ref_b.astype(np.float64)
+
+    def rmse(x, y):
+        return np.sqrt(((x - y) ** 2).reshape(-1, 3).mean(axis=0))
+
+    floor = rmse(ref_a, ref_b)
+    got = rmse(gpu, ref_a)
+    assert np.all(floor > 0.5), floor  # 256 spp is not noise-free: the floor means something
+    assert np.all(got <= 1.5 * floor), (got, floor)
+    lum = lambda img: (img @ np.array([0.2126, 0.7152, 0.0722])).mean()
+    assert abs(lum(gpu) - lum(ref_a)) <= 0.005 * lum(ref_a)
