@@ -220,16 +220,24 @@ __device__ __forceinline__ double fclamp(double x, double lo, double hi) {
     return x;
 }
 
+// The texture kinds a kernel is compiled for: every kind up to and including LEVEL in the
+// order below.  Each kind costs registers wherever textures are evaluated (measured for the
+// path kernel: constant 126 VGPRs, + checker 151, everything 251), so a scene that has no
+// noise or image texture runs a kernel that holds more waves per SIMD.
+enum TextureLevel : int { TEXTURES_CONSTANT = 0, TEXTURES_CHECKER = 1, TEXTURES_IMAGE = 2, TEXTURES_ALL = 3, N_TEXTURE_LEVELS = 4 };
+
 // Texture::value (texture.rs:184-193).  Checker nesting is followed iteratively.
 // `lds_tables` = the scene's first `n_staged` Perlin tables as the shade kernel staged them
 // in LDS (null / 0 when it staged none); other tables are read from global memory.
+// A texture of a kind above LEVEL evaluates to black: the host picks LEVEL from the scene.
+template <int LEVEL>
 __device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, const Surface& h,
                                             const mirt_perlin* lds_tables, uint32_t n_staged) {
     for (int guard = 0; guard < 64; ++guard) {
         const mirt_texture* __restrict__ t = sc.textures + tex;
         const uint32_t kind = t->kind;
         if (kind == MIRT_TEX_CONSTANT) return v3(t->color[0], t->color[1], t->color[2]);
-        if (kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
+        if (LEVEL >= TEXTURES_CHECKER && kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
             // one sin() at a time: the scheduler would interleave three inlined side by side and
             // hold ~100 more registers
             double sines = sin(10.0 * h.p.x);
@@ -240,7 +248,7 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, cons
             tex = (sines < 0.0) ? t->odd : t->even;
             continue;
         }
-        if (kind == MIRT_TEX_NOISE) {  // texture.rs:82-87
+        if (LEVEL >= TEXTURES_ALL && kind == MIRT_TEX_NOISE) {  // texture.rs:82-87
             double turb;
             if (t->perlin < n_staged) {
                 const mirt_perlin* pl = lds_tables + t->perlin;
@@ -253,6 +261,7 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, cons
             const double c = (1.0 * 0.5) * (1.0 + sin(turbulence));
             return v3(c, c, c);
         }
+        if (LEVEL < TEXTURES_IMAGE || kind != MIRT_TEX_IMAGE) break;
         // MIRT_TEX_IMAGE, texture.rs:106-122
         double u, v;
         surface_uv(h, &u, &v);

@@ -396,6 +396,7 @@ struct ShadeResult {
 
 // cls: shade class of the hit shape (SHADE_MISS: none).  `last`: this is the deepest bounce
 // allowed; what would be scattered is multiplied by color(.., 0) = 0 (renderer.rs:99-101).
+template <int TEXTURES>
 __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls, const RayD& r, double hit_t, uint32_t hit_ref,
                                                   const V3& beta, uint64_t stream, uint32_t bounce, bool last,
                                                   const V3& background, const mirt_perlin* lds_tables, uint32_t n_staged) {
@@ -410,7 +411,7 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
     const mirt_material* __restrict__ m = sc.materials + h.material;
     if (cls == SHADE_LIGHT) {
         // material.rs:144-152: no scatter, emit = texture value
-        out.radiance = beta * texture_value(sc, m->texture, h, lds_tables, n_staged);
+        out.radiance = beta * texture_value<TEXTURES>(sc, m->texture, h, lds_tables, n_staged);
         return out;
     }
     if (last) return out;
@@ -444,7 +445,7 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
     } else {  // the lambertian classes, material.rs:51-59
         const V3 target = h.p + h.normal + in_sphere;
         dir = target - h.p;
-        attenuation = texture_value(sc, m->texture, h, lds_tables, n_staged);
+        attenuation = texture_value<TEXTURES>(sc, m->texture, h, lds_tables, n_staged);
     }
     if (scattered) {
         out.alive = true;
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
                 hit_ref = P.hit_ref[slot];
                 if (cls != SHADE_LIGHT && !last) stream = P.stream[slot];
             }
-            const ShadeResult s = shade_path(sc, cls, r, hit_t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
+            const ShadeResult s = shade_path<HAS_NOISE ? TEXTURES_ALL : TEXTURES_IMAGE>(sc, cls, r, hit_t, hit_ref, beta, stream, bounce, last, background, lds_tables,
+                                                                                                 n_staged);
             alive = s.alive;
             if (alive) {
                 P.ox[slot] = s.origin.x; P.oy[slot] = s.origin.y; P.oz[slot] = s.origin.z;
@@ -567,16 +569,20 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
 // work, and the queues' 200 bytes per path and bounce of HBM traffic buy less coherence than
 // they cost.  Results do not depend on the bounce at which this kernel takes over: a path's
 // random numbers are a function of (pixel, sample, bounce) alone.
-constexpr int PATHS_BLOCK = 256;
+// Workgroup size and waves per SIMD by texture level (registers: 126 / 151 / 251 VGPRs).  With
+// the tree in LDS one workgroup fills the CU and shares one copy of the tree; without, small
+// workgroups are placed as the registers allow.
+__host__ __device__ constexpr int paths_waves(int textures) { return textures == TEXTURES_CONSTANT ? 4 : (textures == TEXTURES_CHECKER ? 3 : 2); }
+__host__ __device__ constexpr int paths_block(int textures, bool tree_in_lds) { return tree_in_lds ? 256 * paths_waves(textures) : 256; }
 // bits 0-7: as in traverse_persistent; bits 8-15: lanes waiting to be shaded that trigger
 // shading; bits 16-23: empty lanes that trigger a refill from the queue
 constexpr uint32_t PATHS_TUNING_DEFAULT = 2u | (48u << 8) | (16u << 16);
 
-#ifndef MIRT_PATHS_WAVES
-#define MIRT_PATHS_WAVES 2  // waves per SIMD the register allocation of k_paths aims at
-#endif
-template <class StackT, bool HAS_NOISE, bool TREE_IN_LDS>
-__global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_PATHS_WAVES))) void k_paths(DScene sc, Paths P, RenderParams rp, uint32_t bounce0, uint32_t stack_levels, uint32_t tuning) {
+template <class StackT, int TEXTURES, bool TREE_IN_LDS>
+__global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(
+    DScene sc, Paths P, RenderParams rp, uint32_t bounce0, uint32_t stack_levels, uint32_t tuning) {
+    constexpr int PATHS_BLOCK = paths_block(TEXTURES, TREE_IN_LDS);
+    constexpr bool HAS_NOISE = TEXTURES >= TEXTURES_ALL;
     // dynamic LDS: [level][PATHS_BLOCK] stack entries, then (TREE_IN_LDS) nodes and shape parameters
     extern __shared__ __align__(16) char smem[];
     __shared__ mirt_perlin s_perlin[HAS_NOISE ? PERLIN_STAGED : 1];
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
                     hit_ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
                 }
                 const bool last = bounce + 1 == rp.max_depth;
-                const ShadeResult s = shade_path(sc, cls, walk.r, h.t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
+                const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
                 if (s.alive) {
                     RayD r;
                     r.o = s.origin;

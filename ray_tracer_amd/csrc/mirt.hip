@@ -86,6 +86,7 @@ struct mirt_scene {
     uint32_t height = 0;        // levels of inner nodes on the longest root-to-leaf chain
     bool has_bvh = false;
     bool has_noise = false;
+    int texture_level = 0;      // TextureLevel: the highest texture kind the scene holds
     bool regrouped = false;     // fast tree = SAH over the reference's leaf groups (else: reference topology)
     int cu_count = 0;
     // One block of device memory a render call left behind for the next one (the per-pass
@@ -254,7 +255,16 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
         shapes[i].material = s.material;
         shapes[i].cls = shade_class_of(desc, desc->materials[s.material]);
     }
-    for (uint32_t i = 0; i < desc->n_textures; ++i) has_noise |= desc->textures[i].kind == MIRT_TEX_NOISE;
+    int texture_level = TEXTURES_CONSTANT;
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        has_noise |= desc->textures[i].kind == MIRT_TEX_NOISE;
+        switch (desc->textures[i].kind) {
+            case MIRT_TEX_CHECKER: texture_level = std::max<int>(texture_level, TEXTURES_CHECKER); break;
+            case MIRT_TEX_IMAGE: texture_level = std::max<int>(texture_level, TEXTURES_IMAGE); break;
+            case MIRT_TEX_NOISE: texture_level = std::max<int>(texture_level, TEXTURES_ALL); break;
+            default: break;
+        }
+    }
 
     std::vector<uint32_t> tkinds;
     std::vector<double> tparams;
@@ -287,6 +297,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     sc->device = dev;
     sc->has_bvh = desc->nodes != nullptr;
     sc->has_noise = has_noise;
+    sc->texture_level = texture_level;
     sc->height = height;
     DeviceArena arena;
     auto upload = [&](auto** dptr, const auto* src, size_t count, size_t min_count = 1) -> hipError_t {
@@ -646,40 +657,44 @@ int blocks_per_cu(K kernel, int fallback) {
 struct PathsPlan {
     bool stack16 = true;
     bool tree_in_lds = false;
+    int block = 256;
     size_t lds_bytes = 0;
     uint32_t levels = 1;
     int per_cu = 1;
     const void* kernel = nullptr;
 };
 
-template <class StackT, bool NOISE, bool TREE>
-void paths_kernel_for(PathsPlan* p) {
-    p->kernel = (const void*)k_paths<StackT, NOISE, TREE>;
+template <class StackT, bool TREE>
+const void* paths_kernel_for(int textures) {
+    switch (textures) {
+        case TEXTURES_CONSTANT: return (const void*)k_paths<StackT, TEXTURES_CONSTANT, TREE>;
+        case TEXTURES_CHECKER: return (const void*)k_paths<StackT, TEXTURES_CHECKER, TREE>;
+        case TEXTURES_IMAGE: return (const void*)k_paths<StackT, TEXTURES_IMAGE, TREE>;
+        default: return (const void*)k_paths<StackT, TEXTURES_ALL, TREE>;
+    }
 }
 
 hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     PathsPlan p;
+    const int textures = scene->texture_level;
     p.levels = std::max<uint32_t>(scene->height, 1);
     p.stack16 = scene->d.n_nodes < 65536u;
-    const size_t stack = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4, PATHS_BLOCK);
     const size_t tree = trav_nodes_bytes(scene->d.n_nodes) + (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
-    const size_t fixed = scene->has_noise ? sizeof(mirt_perlin) * PERLIN_STAGED : 0;
-    // two workgroups per CU (the kernel's registers allow no more) must fit with their own copy
-    p.tree_in_lds = scene->d.n_nodes > 0 && 2 * (stack + tree + fixed) <= TRAV_LDS_BUDGET;
-    p.lds_bytes = stack + (p.tree_in_lds ? tree : 0);
-    if (p.stack16) {
-        if (scene->has_noise) p.tree_in_lds ? paths_kernel_for<uint16_t, true, true>(&p) : paths_kernel_for<uint16_t, true, false>(&p);
-        else p.tree_in_lds ? paths_kernel_for<uint16_t, false, true>(&p) : paths_kernel_for<uint16_t, false, false>(&p);
-    } else {
-        if (scene->has_noise) p.tree_in_lds ? paths_kernel_for<uint32_t, true, true>(&p) : paths_kernel_for<uint32_t, true, false>(&p);
-        else p.tree_in_lds ? paths_kernel_for<uint32_t, false, true>(&p) : paths_kernel_for<uint32_t, false, false>(&p);
-    }
+    const size_t fixed = textures >= TEXTURES_ALL ? sizeof(mirt_perlin) * PERLIN_STAGED : 0;
+    // tree in LDS: ONE workgroup per CU, as many waves as the registers allow, sharing one copy
+    const int big = paths_block(textures, true);
+    const size_t big_stack = trav_stack_bytes(p.levels, 2, big);
+    p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && big_stack + tree + fixed <= TRAV_LDS_BUDGET;
+    p.block = paths_block(textures, p.tree_in_lds);
+    p.lds_bytes = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4, p.block) + (p.tree_in_lds ? tree : 0);
+    if (p.tree_in_lds) p.kernel = paths_kernel_for<uint16_t, true>(textures);
+    else p.kernel = p.stack16 ? paths_kernel_for<uint16_t, false>(textures) : paths_kernel_for<uint32_t, false>(textures);
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(p.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
     }
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, p.kernel, PATHS_BLOCK, p.lds_bytes) != hipSuccess || n <= 0) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, p.kernel, p.block, p.lds_bytes) != hipSuccess || n <= 0) n = 1;
     p.per_cu = std::min(n, 8);
     *out = p;
     return hipSuccess;
@@ -687,9 +702,9 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
 
 // expected: paths that will probably enter (the kernel copes with any number).
 hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Paths& P, const RenderParams& rp, uint32_t bounce,
-                       uint32_t expected, hipStream_t stream) {
+                        uint32_t expected, hipStream_t stream) {
     // few paths: spread them over as many waves as there are, a path's bounces are sequential
-    const size_t want = ((size_t)expected + PATHS_BLOCK - 1) / PATHS_BLOCK;
+    const size_t want = ((size_t)expected + plan.block - 1) / plan.block;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)scene->cu_count * plan.per_cu));
     // development aid: MIRT_PATHS_TUNING overrides the scheduling parameters of the kernel
     static const uint32_t tuning_default = [] {
@@ -701,7 +716,7 @@ hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Pa
     RenderParams params = rp;
     uint32_t levels = plan.levels, tuning = tuning_default;
     void* args[] = {&sc, &paths, &params, &bounce, &levels, &tuning};
-    return hipLaunchKernel(plan.kernel, dim3(grid), dim3(PATHS_BLOCK), args, plan.lds_bytes, stream);
+    return hipLaunchKernel(plan.kernel, dim3(grid), dim3(plan.block), args, plan.lds_bytes, stream);
 }
 
 int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
