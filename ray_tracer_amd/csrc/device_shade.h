@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mirt_rng.h"
+#include "checker_sin.h"
 #include "device_intersect.h"
 
 namespace mirt {
@@ -213,6 +214,12 @@ __device__ __forceinline__ double perlin_turbulence(const double* __restrict__ v
 }
 
 // ---------------------------------------------------------------------- textures
+// sin() of the checker: the register-light form for every argument a scene of sane size
+// produces, the library's behind a call (so that its code stays out of the kernels' bodies)
+// for the rest.
+__device__ __noinline__ double sin_rare(double x) { return sin(x); }
+__device__ __forceinline__ double checker_sin(double x) { return fabs(x) < SIN_SMALL_LIMIT ? sin_small(x) : sin_rare(x); }
+
 // texture.rs:195-205
 __device__ __forceinline__ double fclamp(double x, double lo, double hi) {
     if (x < lo) x = lo;
@@ -238,13 +245,12 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, cons
         const uint32_t kind = t->kind;
         if (kind == MIRT_TEX_CONSTANT) return v3(t->color[0], t->color[1], t->color[2]);
         if (LEVEL >= TEXTURES_CHECKER && kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
-            // one sin() at a time: the scheduler would interleave three inlined side by side and
-            // hold ~100 more registers
-            double sines = sin(10.0 * h.p.x);
+            // one sine at a time (side by side the scheduler would hold all three in registers)
+            double sines = checker_sin(10.0 * h.p.x);
             __builtin_amdgcn_sched_barrier(0);
-            sines = sines * sin(10.0 * h.p.y);
+            sines = sines * checker_sin(10.0 * h.p.y);
             __builtin_amdgcn_sched_barrier(0);
-            sines = sines * sin(10.0 * h.p.z);
+            sines = sines * checker_sin(10.0 * h.p.z);
             tex = (sines < 0.0) ? t->odd : t->even;
             continue;
         }

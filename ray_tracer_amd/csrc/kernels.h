@@ -569,10 +569,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
 // work, and the queues' 200 bytes per path and bounce of HBM traffic buy less coherence than
 // they cost.  Results do not depend on the bounce at which this kernel takes over: a path's
 // random numbers are a function of (pixel, sample, bounce) alone.
-// Workgroup size and waves per SIMD by texture level (registers: 126 / 151 / 251 VGPRs).  With
+// Workgroup size and waves per SIMD by texture level (registers: 126 / 128 / 228 / 254 VGPRs).  With
 // the tree in LDS one workgroup fills the CU and shares one copy of the tree; without, small
 // workgroups are placed as the registers allow.
-__host__ __device__ constexpr int paths_waves(int textures) { return textures == TEXTURES_CONSTANT ? 4 : (textures == TEXTURES_CHECKER ? 3 : 2); }
+__host__ __device__ constexpr int paths_waves(int textures) { return textures <= TEXTURES_CHECKER ? 4 : 2; }
 __host__ __device__ constexpr int paths_block(int textures, bool tree_in_lds) { return tree_in_lds ? 256 * paths_waves(textures) : 256; }
 // bits 0-7: as in traverse_persistent; bits 8-15: lanes waiting to be shaded that trigger
 // shading; bits 16-23: empty lanes that trigger a refill from the queue

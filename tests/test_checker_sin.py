@@ -1,0 +1,57 @@
+"""ray_tracer_amd/csrc/checker_sin.h against the host library's sin(): the header is plain
+C++ (no FMA contraction), so what g++ computes here is what the device computes."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SOURCE = r"""
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include "checker_sin.h"
+static int64_t ulps(double a, double b) {
+    int64_t x, y;
+    std::memcpy(&x, &a, 8);
+    std::memcpy(&y, &b, 8);
+    if (x < 0) x = INT64_MIN - x;
+    if (y < 0) y = INT64_MIN - y;
+    return x > y ? x - y : y - x;
+}
+int main() {
+    std::mt19937_64 g(1);
+    int64_t worst = 0;
+    long sign_mismatch = 0, n = 0;
+    auto check = [&](double x) {
+        const double a = mirt::sin_small(x), b = std::sin(x);
+        worst = std::max(worst, ulps(a, b));
+        if ((a < 0) != (b < 0) && b != 0) ++sign_mismatch;
+        ++n;
+    };
+    std::uniform_real_distribution<double> small(-10, 10), mid(-1e4, 1e4), big(-mirt::SIN_SMALL_LIMIT, mirt::SIN_SMALL_LIMIT);
+    for (int i = 0; i < 1000000; ++i) { check(small(g)); check(mid(g)); check(big(g)); }
+    // next to the multiples of pi/2, where the reduction cancels nearly everything
+    for (int k = -1048000; k <= 1048000; k += 7) {
+        const double x = k * 1.5707963267948966;
+        check(x); check(std::nextafter(x, 1e9)); check(std::nextafter(x, -1e9));
+    }
+    for (double x = 1e-300; x < 1; x *= 1.7) { check(x); check(-x); }
+    check(0.0);
+    std::printf("%lld %ld %ld\n", (long long)worst, sign_mismatch, n);
+    return 0;
+}
+"""
+
+
+def test_sin_small_is_within_one_ulp_and_never_flips_a_sign(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text(SOURCE)
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "ray_tracer_amd", "csrc"),
+                    str(src), "-o", str(exe)], check=True)
+    worst, mismatches, n = map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert n > 3_000_000
+    assert worst <= 1       # ulps against libm
+    assert mismatches == 0  # the checker texture only uses the sign
