@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBMIRT_PATH = os.path.join(_HERE, "csrc", "libmirt.so")
+# MIRT_LIBMIRT: development builds of the same library (e.g. csrc/libmirt_stats.so with clock statistics)
+LIBMIRT_PATH = os.environ.get("MIRT_LIBMIRT") or os.path.join(_HERE, "csrc", "libmirt.so")
 LIBHOST_PATH = os.path.join(_HERE, "host", "libmirt_host.so")
 
 c_double3 = C.c_double * 3

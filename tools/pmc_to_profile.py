@@ -1,0 +1,33 @@
+"""Turns tools/pmc_summary.py output into the per-launch record kept under profiles/.
+usage: python tools/pmc_to_profile.py <pmc_summary.json> <paths_per_launch> <command string> > profiles/rNN_pmc_k_paths.json"""
+import json
+import sys
+
+
+def main(path, paths_per_launch, command):
+    with open(path) as f:
+        summary = json.load(f)
+    name = next(k for k in summary if "k_paths" in k)
+    c = summary[name]
+    n = c.pop("_dispatches")
+    per_launch = {k: v / n for k, v in c.items()}
+    # FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950 a 128-byte read request counts as 64 bytes
+    hbm = (2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0
+    out = {
+        "command": command,
+        "kernel": name,
+        "paths_per_launch": paths_per_launch,
+        "counters_per_launch": dict(sorted(per_launch.items()), _dispatches=n),
+        "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; SQ_*_CYCLES and SQ_ACTIVE_INST_* in quad-cycles",
+        "hbm_bytes_per_launch": hbm,
+        "hbm_bytes_note": "FETCH_SIZE doubled (gfx950 counts 128-byte read requests as 64 bytes); WRITE_SIZE as reported",
+        "hbm_bytes_per_path": hbm / paths_per_launch,
+        "lanes_active_per_valu_instruction": per_launch["SQ_THREAD_CYCLES_VALU"] / per_launch["SQ_INSTS_VALU"],
+        "valu_busy_share_of_wave_cycles": 4.0 * per_launch["SQ_ACTIVE_INST_VALU"] / per_launch["SQ_WAVE_CYCLES"],
+        "valu_instructions_per_path": per_launch["SQ_INSTS_VALU"] * 64.0 / paths_per_launch,
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3])
