@@ -1,34 +1,36 @@
-// accel_build.h -- host side: turns the reference's BVHMember array into the tree
-// of DNodes the fast closest-hit kernel walks.
+// accel_build.h -- host side: what the fast closest-hit query walks instead of the
+// reference's tree, and why its answers are still the reference's.
 //
-// Two builders:
+// The reference (src/bvh.rs:37-80) returns, for a ray and (t_min, t_max), the hit with the
+// smallest t -- equal t: the larger shape index -- among the shapes that
+//   (a) are REACHED: AABB::hit(ray, t_min, t_max) passes for the bounds of every
+//       BVHMember::Node above the shape's leaf, and
+//   (b) are HIT: Shape::hit(ray, t_min, t_max) returns Some.
+// Its tree is a random-axis median split (bvh.rs:146, 202), poor at keeping rays away from
+// shapes, and because no query shortens t_max on the way (bvh.rs:65-66) it tests every
+// reached shape.  The fast query separates the two roles the reference's boxes play:
 //
-//  flatten_reference()  keeps the reference's topology (src/bvh.rs:137-237): one
-//      DNode per BVHMember::Node, children boxes copied into the parent.
+//  gates   (a) is decided with the reference's own boxes and arithmetic, bit for bit, but
+//          only for a shape that is about to win.  Every Node's bounds is the component-wise
+//          min/max over all shapes below it (bvh.rs:185, 228-229; aabb.rs:53-71), so a
+//          parent's box contains each inner child's box component by component, and the
+//          slab test (aabb.rs:24-51) is monotone in the box: subtraction and multiplication
+//          by a fixed 1/d round monotonically; a NaN from 0 * inf is dropped by max/min and
+//          only ever removes a constraint.  Hence "child box passes => parent box passes
+//          => ... => root passes", and (a) equals "the box of the leaf's OWN parent
+//          passes".  build_gates() keeps one gate per Node and lets every shape point at its
+//          parent's; when a caller's boxes do not nest (checked), each gate also points at
+//          the gate above it and the whole chain is tested.
 //
-//  regroup()  keeps the reference's DECISIONS but not its topology.  In the
-//      reference a leaf is tested iff every ancestor's box passes AABB::hit
-//      (src/bvh.rs:61-66).  Every Node's bounds is the component-wise min/max
-//      over all shapes below it (bvh.rs:185, 228-229; aabb.rs:53-71), so a
-//      parent's box contains each inner child's box component by component.
-//      The slab test (aabb.rs:24-51) is monotone in the box: with
-//      parent.min <= child.min and parent.max >= child.max, every t0 of the
-//      parent is <= the child's and every t1 >= the child's (subtraction and
-//      multiplication by a fixed 1/d round monotonically; a NaN from 0 * inf is
-//      dropped by max/min and only ever removes a constraint, and it can appear
-//      for the parent only where the child's bound is no tighter), hence
-//            child box passes  =>  parent box passes  =>  ... => root passes.
-//      So "all ancestors pass" equals "the nearest ancestor that is a Node
-//      passes", i.e. a leaf is tested iff the box of its OWN parent passes.
-//      regroup() therefore collects, for every Node with at least one leaf
-//      child, a GROUP = {that node's exact box, its 1 or 2 leaf children}, and
-//      builds a fresh surface-area-heuristic tree over the groups whose inner
-//      boxes are exact min/max unions of group boxes.  By the same monotonicity
-//      an inner box can only fail when every group below fails, so the fresh
-//      tree never hides a group the reference would have reached, and the group's
-//      own box test -- bit for bit the reference's -- is what admits its leaves.
-//      The precondition (parent boxes contain child boxes) is checked on the
-//      caller's array; if it does not hold, flatten_reference() is used instead.
+//  culling a surface-area-heuristic tree over the shapes' own bounding boxes (f32, widened)
+//          decides which shapes are worth testing.  It may only ever skip a shape that
+//          cannot win: its slab test is conservative (device_traverse.h says how), so a
+//          shape that is hit at t <= the best t so far is always found, reached or not.
+//
+// The query then takes the closest hit among ALL shapes, checks (a) for that one shape, and
+// in the rare case that it fails (a ray grazing a gate within rounding) walks again with (a)
+// checked on every hit.  The closest hit among all shapes, if reached, is the closest among
+// the reached ones, so the answer is the reference's.
 #pragma once
 
 #include <algorithm>
@@ -42,11 +44,13 @@
 namespace mirt {
 
 struct BuiltTree {
-    std::vector<DNode> nodes;
+    std::vector<CNode> nodes;
+    std::vector<DGate> gates;
+    std::vector<uint32_t> gate_of;  // per shape
     uint32_t root_ref = 0;
-    double root_box[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     uint32_t height = 0;  // most stack entries a traversal can hold + 1
-    bool regrouped = false;
+    double time_lo = -std::numeric_limits<double>::infinity();
+    double time_hi = std::numeric_limits<double>::infinity();
 };
 
 namespace accel {
@@ -73,13 +77,12 @@ inline double half_area(const Box& b) {
 }
 
 // `tk` = TraverseKind of every shape (how the fast traversal tests it).
-inline uint32_t leaf_ref(const uint32_t* tk, uint32_t shape, bool gated) {
-    return REF_LEAF | (gated ? REF_GATED : 0u) | (tk[shape] << REF_KIND_SHIFT) | shape;
-}
+inline uint32_t leaf_ref(const uint32_t* tk, uint32_t shape) { return REF_LEAF | (tk[shape] << REF_KIND_SHIFT) | shape; }
 
-// Bounding box of a shape, used only to order and distance-prune leaf children of a
-// group node (never to reject).  A moving sphere is boxed over its own time span.
-inline Box advisory_box(const mirt_shape& s) {
+// Bounding box of the points at which Shape::hit can report a hit (src/hittable.rs:105-137,
+// 185-207, 249-271, 313-335, 432-445, 487-521), whatever the sign of a radius or the order
+// of a cube's corners.  A moving sphere is boxed over its own time span [ts, te].
+inline Box shape_box(const mirt_shape& s) {
     Box b;
     auto sphere = [](const double c[3], double r, Box* out) {
         const double a = std::fabs(r);
@@ -88,7 +91,6 @@ inline Box advisory_box(const mirt_shape& s) {
             out->hi[k] = c[k] + a;
         }
     };
-    const double pad = 0.0001;
     switch (s.kind) {
         case MIRT_SHAPE_SPHERE: sphere(s.f, s.f[3], &b); break;
         case MIRT_SHAPE_MOVING_SPHERE: {
@@ -98,37 +100,48 @@ inline Box advisory_box(const mirt_shape& s) {
             b = box_union(b, b2);
             break;
         }
-        case MIRT_SHAPE_XY_RECT:
-            b = Box{{s.f[0], s.f[2], s.f[4] - pad}, {s.f[1], s.f[3], s.f[4] + pad}};
-            break;
-        case MIRT_SHAPE_XZ_RECT:
-            b = Box{{s.f[0], s.f[4] - pad, s.f[2]}, {s.f[1], s.f[4] + pad, s.f[3]}};
-            break;
-        case MIRT_SHAPE_YZ_RECT:
-            b = Box{{s.f[4] - pad, s.f[0], s.f[2]}, {s.f[4] + pad, s.f[1], s.f[3]}};
-            break;
-        default:  // cube
+        case MIRT_SHAPE_XY_RECT: b = Box{{s.f[0], s.f[2], s.f[4]}, {s.f[1], s.f[3], s.f[4]}}; break;
+        case MIRT_SHAPE_XZ_RECT: b = Box{{s.f[0], s.f[4], s.f[2]}, {s.f[1], s.f[4], s.f[3]}}; break;
+        case MIRT_SHAPE_YZ_RECT: b = Box{{s.f[4], s.f[0], s.f[2]}, {s.f[4], s.f[1], s.f[3]}}; break;
+        default:  // cube: six rects on the faces of [p0, p1]
             for (int k = 0; k < 3; ++k) {
-                b.lo[k] = std::fmin(s.f[k], s.f[3 + k]) - pad;
-                b.hi[k] = std::fmax(s.f[k], s.f[3 + k]) + pad;
+                b.lo[k] = std::fmin(s.f[k], s.f[3 + k]);
+                b.hi[k] = std::fmax(s.f[k], s.f[3 + k]);
             }
             break;
     }
-    return b;
-}
-
-inline void put_box(DNode& n, int c, const Box& b) {
-    for (int a = 0; a < 3; ++a) {
-        n.box[c][a][0] = b.lo[a];
-        n.box[c][a][1] = b.hi[a];
+    // anything not finite: no culling for this shape
+    for (int k = 0; k < 3; ++k) {
+        if (!std::isfinite(b.lo[k])) b.lo[k] = -std::numeric_limits<double>::infinity();
+        if (!std::isfinite(b.hi[k])) b.hi[k] = std::numeric_limits<double>::infinity();
     }
+    return b;
 }
 
-inline Box member_box(const mirt_bvh_member& m) {
-    Box b;
-    std::memcpy(b.lo, m.bmin, sizeof b.lo);
-    std::memcpy(b.hi, m.bmax, sizeof b.hi);
-    return b;
+// The widening the f32 slab test of device_traverse.h relies on: every bound moves outward by
+// 2^-19 of its magnitude (that test's rounding errors proportional to the bound) plus 1e-6 of
+// the box's size and a small absolute amount (hits the f64 shape tests accept lie on the
+// shape only up to THEIR rounding), then to the next f32 outward.
+constexpr double CULL_REL = 1.0 / 524288.0;  // 2^-19
+inline float f32_below(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+inline float f32_above(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+inline void put_box(CNode& n, int c, const Box& b) {
+    double size = 0.0;
+    for (int a = 0; a < 3; ++a)
+        if (std::isfinite(b.hi[a] - b.lo[a])) size = std::fmax(size, b.hi[a] - b.lo[a]);
+    const double slack = 1.0e-6 * size + 1.0e-30;
+    for (int a = 0; a < 3; ++a) {
+        n.b[a][0][c] = f32_below(b.lo[a] - (std::fabs(b.lo[a]) * CULL_REL + slack));
+        n.b[a][1][c] = f32_above(b.hi[a] + (std::fabs(b.hi[a]) * CULL_REL + slack));
+    }
 }
 
 }  // namespace accel
@@ -166,58 +179,6 @@ inline void traversal_shapes(const mirt_scene_desc* desc, std::vector<uint32_t>*
     }
 }
 
-// One DNode per BVHMember::Node, numbered breadth-first from the root.
-inline BuiltTree flatten_reference(const mirt_scene_desc* desc, const uint32_t* tk) {
-    using namespace accel;
-    BuiltTree t;
-    const uint32_t nm = desc->n_nodes;
-    const mirt_bvh_member& root = desc->nodes[nm - 1];
-    if (root.is_leaf) {
-        t.root_ref = leaf_ref(tk, root.shape, false);
-        t.height = 1;
-        return t;
-    }
-    std::vector<uint32_t> order, node_of(nm, 0xFFFFFFFFu), level(nm, 0);
-    order.push_back(nm - 1);
-    node_of[nm - 1] = 0;
-    level[nm - 1] = 1;
-    for (size_t k = 0; k < order.size(); ++k) {
-        const mirt_bvh_member& m = desc->nodes[order[k]];
-        t.height = std::max(t.height, level[order[k]]);
-        for (uint32_t child : {m.left, m.right})
-            if (!desc->nodes[child].is_leaf) {
-                node_of[child] = (uint32_t)order.size();
-                level[child] = level[order[k]] + 1;
-                order.push_back(child);
-            }
-    }
-    t.nodes.resize(order.size());
-    for (size_t k = 0; k < order.size(); ++k) {
-        const mirt_bvh_member& m = desc->nodes[order[k]];
-        DNode& n = t.nodes[k];
-        std::memset(&n, 0, sizeof n);
-        const uint32_t kids[2] = {m.left, m.right};
-        for (int c = 0; c < 2; ++c) {
-            const mirt_bvh_member& ch = desc->nodes[kids[c]];
-            if (ch.is_leaf) {
-                n.child[c] = leaf_ref(tk, ch.shape, false);
-                put_box(n, c, advisory_box(desc->shapes[ch.shape]));
-            } else {
-                n.child[c] = node_of[kids[c]];
-                put_box(n, c, member_box(ch));
-            }
-        }
-    }
-    t.root_ref = 0;
-    const Box rb = member_box(root);
-    for (int a = 0; a < 3; ++a) {
-        t.root_box[a][0] = rb.lo[a];
-        t.root_box[a][1] = rb.hi[a];
-    }
-    t.height += 1;
-    return t;
-}
-
 // True when every Node's box contains the boxes of its inner children component-wise.
 inline bool boxes_nest(const mirt_scene_desc* desc) {
     for (uint32_t i = 0; i < desc->n_nodes; ++i) {
@@ -233,20 +194,56 @@ inline bool boxes_nest(const mirt_scene_desc* desc) {
     return true;
 }
 
+// One gate per BVHMember::Node; every shape points at its parent's.
+inline void build_gates(const mirt_scene_desc* desc, BuiltTree* t) {
+    const uint32_t nm = desc->n_nodes;
+    const bool nest = boxes_nest(desc);
+    t->gate_of.assign(desc->n_shapes, NO_GATE);
+    std::vector<uint32_t> gate_index(nm, NO_GATE);
+    // members come children first (post-order); walk from the root down so that a node's
+    // parent gate exists when the node's own is made
+    for (uint32_t i = nm; i-- > 0;) {
+        const mirt_bvh_member& m = desc->nodes[i];
+        if (m.is_leaf) continue;
+        if (gate_index[i] == NO_GATE) {  // the root (or, in a malformed array, an orphan)
+            gate_index[i] = (uint32_t)t->gates.size();
+            DGate g;
+            std::memset(&g, 0, sizeof g);
+            g.next = NO_GATE;
+            t->gates.push_back(g);
+        }
+        DGate& g = t->gates[gate_index[i]];
+        for (int a = 0; a < 3; ++a) {
+            g.box[a][0] = m.bmin[a];
+            g.box[a][1] = m.bmax[a];
+        }
+        for (uint32_t child : {m.left, m.right}) {
+            const mirt_bvh_member& ch = desc->nodes[child];
+            if (ch.is_leaf) {
+                t->gate_of[ch.shape] = gate_index[i];
+            } else {
+                gate_index[child] = (uint32_t)t->gates.size();
+                DGate cg;
+                std::memset(&cg, 0, sizeof cg);
+                cg.next = nest ? NO_GATE : gate_index[i];
+                t->gates.push_back(cg);
+            }
+        }
+    }
+}
+
 namespace accel {
 
-struct Group {
-    Box box;             // exact bounds of the reference node the leaves hang from
-    uint32_t shapes[2];  // its leaf children, left to right
-    uint32_t n_shapes;
+struct Item {
+    Box box;
+    uint32_t shape;
     double centroid[3];
 };
 
 struct Builder {
-    const mirt_scene_desc* desc;
     const uint32_t* tk;
-    std::vector<Group>& groups;
-    std::vector<DNode>& out;
+    std::vector<Item>& items;
+    std::vector<CNode>& out;
     uint32_t max_height;
     uint32_t height_seen = 0;
 
@@ -256,32 +253,13 @@ struct Builder {
         Box box;
     };
 
-    // A group becomes a gated leaf reference -- the parent's copy of the group box admits
-    // it -- for one shape, or for two shapes with consecutive indices (what bvh.rs:187-188
-    // always produces).  Two shapes that are not neighbours get a DNode whose children
-    // are ungated leaves: the parent's copy of the group box admitted the node, nothing
-    // more gates the shapes.
-    Sub emit_group(const Group& g, uint32_t depth) {
-        height_seen = std::max(height_seen, depth + 1);
-        if (g.n_shapes == 1) return Sub{leaf_ref(tk, g.shapes[0], true), g.box};
-        if (g.shapes[1] == g.shapes[0] + 1) {
-            const uint32_t ref = leaf_ref(tk, g.shapes[0], true) | REF_PAIR | (tk[g.shapes[1]] << REF_KIND2_SHIFT);
-            return Sub{ref, g.box};
-        }
-        DNode n;
-        std::memset(&n, 0, sizeof n);
-        for (int c = 0; c < 2; ++c) {
-            n.child[c] = leaf_ref(tk, g.shapes[c], false);
-            put_box(n, c, advisory_box(desc->shapes[g.shapes[c]]));
-        }
-        out.push_back(n);
-        return Sub{(uint32_t)(out.size() - 1), g.box};
-    }
-
-    // Builds the subtree over groups[first, first+count) at `depth` (root = 0).
+    // Builds the subtree over items[first, first+count) at `depth` (root = 0).
     Sub build(uint32_t first, uint32_t count, uint32_t depth) {
-        if (count == 1) return emit_group(groups[first], depth);
-        Group* g = groups.data() + first;
+        if (count == 1) {
+            height_seen = std::max(height_seen, depth + 1);
+            return Sub{leaf_ref(tk, items[first].shape), items[first].box};
+        }
+        Item* g = items.data() + first;
         // levels still available below this node
         const uint32_t budget = max_height > depth + 2 ? max_height - depth - 2 : 0;
         uint32_t need = 0;
@@ -293,7 +271,7 @@ struct Builder {
             double best = std::numeric_limits<double>::infinity();
             std::vector<double> right_area(count);
             for (int a = 0; a < 3; ++a) {
-                std::sort(g, g + count, [a](const Group& x, const Group& y) { return x.centroid[a] < y.centroid[a]; });
+                std::sort(g, g + count, [a](const Item& x, const Item& y) { return x.centroid[a] < y.centroid[a]; });
                 Box acc = g[count - 1].box;
                 for (uint32_t i = count - 1; i > 0; --i) {
                     acc = box_union(acc, g[i].box);
@@ -320,12 +298,12 @@ struct Builder {
                 if (all.hi[a] - all.lo[a] > all.hi[axis] - all.lo[axis]) axis = a;
             split = count / 2;
         }
-        std::sort(g, g + count, [axis](const Group& x, const Group& y) { return x.centroid[axis] < y.centroid[axis]; });
+        std::sort(g, g + count, [axis](const Item& x, const Item& y) { return x.centroid[axis] < y.centroid[axis]; });
         const uint32_t self = (uint32_t)out.size();
         out.emplace_back();
         const Sub l = build(first, split, depth + 1);
         const Sub r = build(first + split, count - split, depth + 1);
-        DNode& n = out[self];
+        CNode& n = out[self];
         std::memset(&n, 0, sizeof n);
         n.child[0] = l.ref;
         n.child[1] = r.ref;
@@ -337,41 +315,35 @@ struct Builder {
 
 }  // namespace accel
 
-// Surface-area-heuristic tree over the reference's leaf groups.  Requires boxes_nest(desc).
-inline BuiltTree regroup(const mirt_scene_desc* desc, const uint32_t* tk, uint32_t max_height) {
+// Gates from the reference's tree, culling tree over the shapes' own boxes.
+inline BuiltTree build_fast_tree(const mirt_scene_desc* desc, const uint32_t* tk, uint32_t max_height) {
     using namespace accel;
     BuiltTree t;
-    t.regrouped = true;
-    const uint32_t nm = desc->n_nodes;
-    const mirt_bvh_member& root = desc->nodes[nm - 1];
-    if (root.is_leaf) {
-        t.root_ref = leaf_ref(tk, root.shape, false);
+    build_gates(desc, &t);
+    std::vector<Item> items(desc->n_shapes);
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        const mirt_shape& s = desc->shapes[i];
+        items[i].shape = i;
+        items[i].box = shape_box(s);
+        for (int a = 0; a < 3; ++a) {
+            const double c = 0.5 * items[i].box.lo[a] + 0.5 * items[i].box.hi[a];
+            items[i].centroid[a] = std::isfinite(c) ? c : 0.0;
+        }
+        if (s.kind == MIRT_SHAPE_MOVING_SPHERE) {
+            // Moving::center (hittable.rs:550-561) stays between its two end points for ts <= time <= te
+            const double a = std::fmin(s.f[7], s.f[8]), b = std::fmax(s.f[7], s.f[8]);
+            t.time_lo = std::fmax(t.time_lo, a);
+            t.time_hi = std::fmin(t.time_hi, b);
+        }
+    }
+    if (desc->n_shapes == 1) {
+        t.root_ref = leaf_ref(tk, 0);
         t.height = 1;
         return t;
     }
-    std::vector<Group> groups;
-    for (uint32_t i = 0; i < nm; ++i) {
-        const mirt_bvh_member& m = desc->nodes[i];
-        if (m.is_leaf) continue;
-        Group g;
-        g.n_shapes = 0;
-        for (uint32_t child : {m.left, m.right})
-            if (desc->nodes[child].is_leaf) g.shapes[g.n_shapes++] = desc->nodes[child].shape;
-        if (g.n_shapes == 0) continue;
-        g.box = member_box(m);
-        for (int a = 0; a < 3; ++a) {
-            const double c = 0.5 * g.box.lo[a] + 0.5 * g.box.hi[a];
-            g.centroid[a] = std::isfinite(c) ? c : 0.0;
-        }
-        groups.push_back(g);
-    }
-    Builder b{desc, tk, groups, t.nodes, max_height};
-    const Builder::Sub top = b.build(0, (uint32_t)groups.size(), 0);
-    t.root_ref = top.ref;
-    for (int a = 0; a < 3; ++a) {
-        t.root_box[a][0] = top.box.lo[a];
-        t.root_box[a][1] = top.box.hi[a];
-    }
+    Builder b{tk, items, t.nodes, max_height};
+    const Builder::Sub top = b.build(0, desc->n_shapes, 0);
+    t.root_ref = top.ref;  // node 0
     t.height = b.height_seen + 1;
     return t;
 }

@@ -8,39 +8,41 @@
 
 namespace mirt {
 
-// A reference to a BVH child or a stack entry.
-//   bit 31      : 1 = leaf (shapes), 0 = inner node
-//   inner node  : bits 0..30 = index into the DNode array
-//   leaf        : bit 30 = gated: test the shapes only if the box stored beside this
-//                 reference passes the slab test
-//                 bit 29 = pair: two shapes, index and index + 1
-//                 bits 26..28 = TraverseKind of shape `index`
-//                 bits 23..25 = TraverseKind of shape `index + 1` (pair only)
+// A reference to a child of the culling tree.
+//   bit 31      : 1 = leaf (one shape), 0 = inner node
+//   inner node  : bits 0..30 = index into the CNode array
+//   leaf        : bits 26..28 = TraverseKind of the shape
 //                 bits 0..22  = index into the sorted shape array
 constexpr uint32_t REF_LEAF = 0x80000000u;
-constexpr uint32_t REF_GATED = 0x40000000u;
-constexpr uint32_t REF_PAIR = 0x20000000u;
 constexpr uint32_t REF_KIND_SHIFT = 26;
-constexpr uint32_t REF_KIND2_SHIFT = 23;
 constexpr uint32_t REF_INDEX_MASK = 0x007FFFFFu;
 constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^23 - 1
 
-// One inner node of the traversal tree: one 128-byte line (the L2 line size on
-// gfx950) holding the boxes of BOTH children, so that one fetch serves two slab
-// tests and the near child can be taken first.
-//
-// box[c][axis][0/1] = min/max of child c along axis.  For an inner child, or a
-// gated leaf, the slab test of this box decides whether the child is entered.
-// For an ungated leaf child -- a leaf carries no box in the reference and is never
-// slab-tested there (src/bvh.rs:45-48) -- it is the shape's own bounding box, kept
-// only to order and distance-prune, never to reject.  accel_build.h says which
-// boxes these are and why the decisions equal the reference's.
-struct alignas(128) DNode {
-    double box[2][3][2];
+// One inner node of the culling tree (accel_build.h): the boxes of BOTH children as
+// f32, laid out so that one 8-byte read fetches the same bound of the two children and the
+// near / far bound of an axis is picked by address:
+//   b[axis][0][c] = lower bound of child c, b[axis][1][c] = upper bound of child c.
+// The boxes only ever CULL: they are the shapes' own bounding boxes, widened, and a slab
+// test on them is built to pass whenever the reference's f64 arithmetic could accept a hit
+// of a shape below (device_traverse.h).  What admits a hit is the gate of its shape.
+struct alignas(8) CNode {
+    float b[3][2][2];
     uint32_t child[2];
-    uint32_t pad[6];
 };
-static_assert(sizeof(DNode) == 128, "DNode must be one 128-byte line");
+static_assert(sizeof(CNode) == 56, "CNode is 56 bytes");
+
+// The boxes of the reference's tree that decide whether a shape is tested at all: in the
+// reference a leaf is reached iff AABB::hit passes for every BVHMember::Node above it
+// (src/bvh.rs:61-66).  gate_of[shape] names the gate of the shape's parent node; `next`
+// leads to the gate of the next ancestor that still has to be tested (NO_GATE: none).
+// accel_build.h cuts the chain after the first gate when boxes nest.
+constexpr uint32_t NO_GATE = 0xFFFFFFFFu;
+struct alignas(8) DGate {
+    double box[3][2];  // [axis][min,max], the bits of the reference's AABB
+    uint32_t next;
+    uint32_t pad;
+};
+static_assert(sizeof(DGate) == 56, "DGate is 56 bytes");
 
 // One shape: 96 bytes, the first 32 of which are all a sphere test needs.
 struct alignas(32) DShape {
@@ -93,7 +95,9 @@ constexpr int MAX_TREE_HEIGHT = 24;
 
 // What the kernels see (passed by value as a kernel argument).
 struct DScene {
-    const DNode* nodes;              // inner nodes; root = nodes[root_ref] unless the root is a leaf
+    const CNode* nodes;              // culling tree; root = nodes[root_ref] unless the root is a leaf
+    const DGate* gates;              // one per BVHMember::Node of the reference's tree
+    const uint32_t* gate_of;         // per shape: its first gate, or NO_GATE
     const DShape* shapes;            // BVH-sorted order
     const double* tparams;           // TPARAMS_PER_SHAPE doubles per shape, see TraverseKind
     const mirt_bvh_member* members;  // the reference's own member array (post-order, root last)
@@ -105,9 +109,9 @@ struct DScene {
     uint32_t n_members;  // 0 when the scene came without a BVH
     uint32_t n_nodes;
     uint32_t root_ref;  // REF_LEAF|... when the scene has a single shape
-    // bounds of the root BVHMember::Node, [axis][min,max]: every other box lives in
-    // its parent's DNode, the root has no parent.  Tested first, like bvh.rs:61 does.
-    double root_box[3][2];
+    // rays whose time lies outside [time_lo, time_hi] are not culled by boxes at all (a
+    // moving sphere is boxed over its own time span only); -inf, +inf without moving shapes
+    double time_lo, time_hi;
 };
 
 }  // namespace mirt

@@ -1,4 +1,4 @@
-// device_traverse.h -- closest-hit queries against the two-boxes-per-node tree of
+// device_traverse.h -- closest-hit queries against the culling tree and the gates of
 // accel_build.h: the walk of one ray cut into steps (RayWalk), and two drivers that run 64
 // walks per wave -- traverse_persistent (a queue of rays; the extend kernel and
 // mirt_intersect) and the path kernel's own loop in kernels.h.
@@ -10,20 +10,21 @@
 //    that meets leaves parks their shapes in registers; the wave runs node visits for the
 //    lanes that want one and shape tests for the lanes that have parked some, whichever more
 //    lanes wait for, and leaves a loop early when few lanes still want it.
-//  * 128-byte node fetches from 64 different addresses per wave instruction kept waves in
-//    s_waitcnt most of their cycles.  When they fit, the tree's nodes (104 B each) and the
-//    shapes' parameters (80 B each) are staged in LDS once per workgroup.
-//  * The slab test reads the near / far bound of each axis by address (8-byte read at
-//    base + 8 * sign) instead of loading both bounds and selecting.
+//  * The kernels are bound by vector-instruction issue.  A node visit in the reference's f64
+//    arithmetic costs ~40 f64 instructions for two boxes; culling needs no such precision, so
+//    the tree's boxes are f32 and two boxes cost 6 packed FMAs and 8 min/max (slab_pair).
+//    The reference's f64 boxes are consulted once per ray, for the winning shape (confirm).
+//  * When they fit, the tree's nodes (56 B each) and the shapes' parameters (80 B each) are
+//    staged in LDS once per workgroup; the near / far bound of each axis is read by address
+//    (8-byte read at base + 8 * sign) instead of loading both bounds and selecting.
 //  * The per-lane stack lives in LDS as [level][thread] and holds inner-node indices only
 //    (16-bit when the tree has < 65536 nodes).
 //  * traverse_persistent: waves pull chunks of rays from a global counter and request the
 //    next ray of a lane while the current one is traced.
 //
-// Decisions are the reference's (device_intersect.h, accel_build.h): exact slab test with
-// the caller's (t_min, t_max) at every box that admits something, shapes tested with the
-// caller's (t_min, t_max), smallest t wins and equal t goes to the larger shape index, extra
-// distance prune with a relative margin.
+// Decisions are the reference's (device_intersect.h, accel_build.h): shapes tested with the
+// caller's (t_min, t_max), smallest t wins and equal t goes to the larger shape index, the
+// winner must pass the reference's slab test on the boxes above its leaf.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -38,8 +39,8 @@ __device__ __forceinline__ uint32_t mbcnt_lt(unsigned long long mask) {
 }
 
 constexpr uint32_t CUR_DONE = 0x7FFFFFFFu;
-constexpr int NODE_LDS_BYTES = 104;   // box[2][3][2] + child[2] of a DNode
-constexpr int SHAPE_LDS_BYTES = 80;   // DShape::f
+constexpr int NODE_LDS_BYTES = sizeof(CNode);  // 56
+constexpr int SHAPE_LDS_BYTES = 80;            // DShape::f
 constexpr uint32_t TUNING_DEFAULT = 2u | (64u << 8);  // see traverse_persistent
 constexpr uint32_t CHUNK_RAYS = 512;  // most rays a wave takes from the queue per fetch
 
@@ -52,46 +53,17 @@ __host__ __device__ inline uint32_t chunk_rays(uint32_t n, uint32_t waves) {
     return c & ~63u;
 }
 
-// Slab test (aabb.rs:24-51) on the six bounds of a box, already ordered near/far per axis.
-__device__ __forceinline__ bool slab_near_far(double lo_x, double hi_x, double lo_y, double hi_y, double lo_z, double hi_z,
-                                              const RayD& r, const double inv[3], double t_min, double t_max,
-                                              double* entry) {
-    const double t0x = (lo_x - r.o.x) * inv[0], t1x = (hi_x - r.o.x) * inv[0];
-    const double t0y = (lo_y - r.o.y) * inv[1], t1y = (hi_y - r.o.y) * inv[1];
-    const double t0z = (lo_z - r.o.z) * inv[2], t1z = (hi_z - r.o.z) * inv[2];
-    double mn = fmax(t0x, t_min);
-    double mx = fmin(t1x, t_max);
-    mn = fmax(t0y, mn);
-    mx = fmin(t1y, mx);
-    mn = fmax(t0z, mn);
-    mx = fmin(t1z, mx);
-    *entry = mn;
-    return !(mx <= mn);
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Slab test of child c of a node in GLOBAL memory; near/far bound of each axis picked by
-// address: off[a] = 8 if 1/d[a] < 0 else 0.
-__device__ __forceinline__ bool slab_by_address(const char* node, int c, const RayD& r, const double inv[3],
-                                                const uint32_t off[3], double t_min, double t_max, double* entry) {
-    const char* b = node + c * 48;
-    const double lo_x = *reinterpret_cast<const double*>(b + off[0]);
-    const double hi_x = *reinterpret_cast<const double*>(b + (off[0] ^ 8u));
-    const double lo_y = *reinterpret_cast<const double*>(b + 16 + off[1]);
-    const double hi_y = *reinterpret_cast<const double*>(b + 16 + (off[1] ^ 8u));
-    const double lo_z = *reinterpret_cast<const double*>(b + 32 + off[2]);
-    const double hi_z = *reinterpret_cast<const double*>(b + 32 + (off[2] ^ 8u));
-    return slab_near_far(lo_x, hi_x, lo_y, hi_y, lo_z, hi_z, r, inv, t_min, t_max, entry);
-}
-
-// One 8-byte LDS read at byte address `addr` + OFFSET, as exactly one ds_read_b64.
+// One 8-byte read at byte address `addr` + OFFSET of LDS, as exactly one ds_read_b64.
 // Written as inline assembly because, left to itself, the compiler pairs neighbouring
 // 8-byte LDS reads into ds_read2_b64; that instruction banks modulo 32 in four 16-lane
 // groups, and with the 64 lanes of a wave in 64 different nodes it measured ~30 LDS cycles
 // per instruction on gfx950 against ~2 for ds_read_b64 -- the node loop became LDS-bound.
 // The caller must issue lds_wait() before using the value.
 template <int OFFSET>
-__device__ __forceinline__ double lds_read_f64(uint32_t addr) {
-    double v;
+__device__ __forceinline__ f32x2 lds_read_f32x2(uint32_t addr) {
+    f32x2 v;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
     return v;
 }
@@ -126,126 +98,189 @@ enum TraverseStat : int {
 // Where the tree and the shapes are read from.
 struct TraverseLds {
     const char* nodes;   // NODE_LDS_BYTES apart, or nullptr: read DScene::nodes
-    const char* shapes;  // SHAPE_LDS_BYTES apart, or nullptr: read DScene::shapes
+    const char* shapes;  // SHAPE_LDS_BYTES apart, or nullptr: read DScene::tparams
 };
+
+// The culling slab test, f32, for the two children of a node at once.
+//
+// Per ray and axis: inv = 1 / d, and the bound b of a box maps to t = b * inv + c with
+//   c_near = -(o * inv) - E,   c_far = -(o * inv) + E,   E = 2^-19 |o * inv|.
+// It must never report a box as missed that contains a point o + t d, t_min < t <= best t,
+// which the f64 shape tests could accept.  Against the exact (b - o) / d the computed t
+// carries relative errors of at most 2^-24 each from rounding d, o, o * inv, c and the FMA to
+// f32 and 2^-23 from v_rcp_f32, proportional to |b * inv| or |o * inv|; the first kind is
+// covered by the 2^-19 |b| the host moved every bound outward by (accel_build.h: CULL_REL),
+// the second by E -- both more than four times what is needed.  Where the arithmetic leaves
+// the range of f32 (d = 0, |o * inv| > 3e38) the terms become infinities of the safe sign or
+// NaN, and the max/min below drop a NaN operand: the axis then constrains nothing.
+struct CullRay {
+    float inv[3], c_near[3], c_far[3];
+    uint32_t off[3];  // 8 if the ray runs down the axis (near bound = upper) else 0
+    __device__ __forceinline__ void set(const RayD& r, bool cull) {
+        const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float i32 = __builtin_amdgcn_rcpf((float)d[a]);
+            const float p = (float)o[a] * i32;
+            const float e = __builtin_fabsf(p) * 0x1.0p-19f;
+            inv[a] = cull ? i32 : 0.0f;
+            c_near[a] = cull ? -p - e : -__builtin_inff();
+            c_far[a] = cull ? -p + e : __builtin_inff();
+            off[a] = i32 < 0.0f ? 8u : 0u;
+        }
+    }
+};
+
+// entry / exit of both children's boxes for the t-range (t_lo, t_hi]; pass = the range is not empty.
+__device__ __forceinline__ void slab_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32x2 fy, f32x2 nz, f32x2 fz, const CullRay& c,
+                                          float t_lo, float t_hi, float* e0, float* e1, bool* pass0, bool* pass1) {
+    const f32x2 tnx = __builtin_elementwise_fma(nx, (f32x2){c.inv[0], c.inv[0]}, (f32x2){c.c_near[0], c.c_near[0]});
+    const f32x2 tfx = __builtin_elementwise_fma(fx, (f32x2){c.inv[0], c.inv[0]}, (f32x2){c.c_far[0], c.c_far[0]});
+    const f32x2 tny = __builtin_elementwise_fma(ny, (f32x2){c.inv[1], c.inv[1]}, (f32x2){c.c_near[1], c.c_near[1]});
+    const f32x2 tfy = __builtin_elementwise_fma(fy, (f32x2){c.inv[1], c.inv[1]}, (f32x2){c.c_far[1], c.c_far[1]});
+    const f32x2 tnz = __builtin_elementwise_fma(nz, (f32x2){c.inv[2], c.inv[2]}, (f32x2){c.c_near[2], c.c_near[2]});
+    const f32x2 tfz = __builtin_elementwise_fma(fz, (f32x2){c.inv[2], c.inv[2]}, (f32x2){c.c_far[2], c.c_far[2]});
+    const float in0 = fmaxf(fmaxf(fmaxf(tnx.x, tny.x), tnz.x), t_lo);
+    const float in1 = fmaxf(fmaxf(fmaxf(tnx.y, tny.y), tnz.y), t_lo);
+    const float out0 = fminf(fminf(fminf(tfx.x, tfy.x), tfz.x), t_hi);
+    const float out1 = fminf(fminf(fminf(tfx.y, tfy.y), tfz.y), t_hi);
+    *e0 = in0;
+    *e1 = in1;
+    *pass0 = !(out0 < in0);
+    *pass1 = !(out1 < in1);
+}
+
+// A value of f32 not below x * (1 + 1e-6) for x >= 0 (not above, for x < 0), and the mirror
+// image: the culling range (t_lo, t_hi] must contain every t the f64 tests can accept.
+__device__ __forceinline__ float f32_not_below(double x) { return (float)(x + fabs(x) * 2.0e-6); }
+__device__ __forceinline__ float f32_not_above(double x) { return (float)(x - fabs(x) * 2.0e-6); }
 
 // The walk of ONE ray (one lane) through the tree, cut into steps so that a wave can
 // choose, trip by trip, which step to run for which lanes:
-//   begin(ray)            1/d, signs, root box
+//   begin(ray)            per-ray constants of the culling test, root
 //   wants_node()          the lane's next step is a visit of inner node `cur`
 //   wants_leaf()          the lane has parked shapes to test first
 //   node_step()           both children's boxes of `cur`; parks leaves; moves on or pops
 //   leaf_step()           tests one parked shape
-//   finished()            neither: `best` is the closest hit (prim < 0: none)
+//   finished()            neither: `best` is the closest hit (prim < 0: none) -- to be
+//                         confirmed by confirm(); if that fails, begin_careful() and walk again
 // stack: LDS, [level][BLOCK] entries of StackT, this lane's column is `tid`.
 template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS>
 struct RayWalk {
     static constexpr uint32_t Q_KIND_SHIFT = 26;
     RayD r;
-    double inv[3];
-    uint32_t off[3];
+    CullRay cull;
     double dd;
     HitRec best;
-    // no box entered beyond `limit` can hold a hit that beats the best one: best.t plus a
-    // margin, +inf while there is no hit
-    double limit;
+    float t_lo;   // f32 not above t_min
+    float t_hi;   // f32 not below min(t_max, best t): nothing entered beyond it can beat the best hit
     uint32_t cur;
     int sp;
-    // shapes parked for the next leaf steps: TraverseKind << 26 | index, at most four (two
-    // leaf references of up to two shapes each), kept in registers q0 (next out) .. q3
-    uint32_t q0, q1, q2, q3, nq;
+    // shapes parked for the next leaf steps: TraverseKind << 26 | index, at most two (the
+    // two children of one node), kept in registers q0 (next out), q1
+    uint32_t q0, q1, nq;
+    bool careful;  // second walk: a hit counts only if its shape's gates pass
 
     __device__ __forceinline__ void reset() {
         cur = CUR_DONE;
         sp = 0;
         nq = 0;
-        q0 = q1 = q2 = q3 = 0;
+        q0 = q1 = 0;
         best = HitRec{0.0, -1, 0};
-        limit = __builtin_inf();
+        careful = false;
     }
     __device__ __forceinline__ bool wants_node() const { return nq == 0 && cur != CUR_DONE; }
     __device__ __forceinline__ bool wants_leaf() const { return nq != 0; }
     __device__ __forceinline__ bool finished() const { return nq == 0 && cur == CUR_DONE; }
 
-    __device__ __forceinline__ void park_shape(uint32_t entry) {
-        q3 = q2;
-        q2 = q1;
+    __device__ __forceinline__ void park(uint32_t ref) {
         q1 = q0;
-        q0 = entry;
+        q0 = (((ref >> REF_KIND_SHIFT) & 7u) << Q_KIND_SHIFT) | (ref & REF_INDEX_MASK);
         ++nq;
     }
-    __device__ __forceinline__ void park(uint32_t ref) {
-        const uint32_t index = ref & REF_INDEX_MASK;
-        park_shape((((ref >> REF_KIND_SHIFT) & 7u) << Q_KIND_SHIFT) | index);
-        if (ref & REF_PAIR) park_shape((((ref >> REF_KIND2_SHIFT) & 7u) << Q_KIND_SHIFT) | (index + 1));
+
+    __device__ __forceinline__ void start(const DScene& sc, double t_min, double t_max) {
+        t_lo = f32_not_above(t_min);
+        t_hi = f32_not_below(t_max);
+        cur = CUR_DONE;
+        sp = 0;
+        nq = 0;
+        q0 = q1 = 0;
+        best = HitRec{0.0, -1, 0};
+        const uint32_t root = sc.root_ref;
+        if (root & REF_LEAF) park(root);  // a one-shape world: bare leaf (bvh.rs:179-180)
+        else cur = root;
     }
 
     __device__ __forceinline__ void begin(const DScene& sc, const RayD& ray, double t_min, double t_max) {
         r = ray;
-        inv[0] = 1.0 / r.d.x;  // aabb.rs:33, once per ray instead of once per box
-        inv[1] = 1.0 / r.d.y;
-        inv[2] = 1.0 / r.d.z;
-        off[0] = inv[0] < 0.0 ? 8u : 0u;  // aabb.rs:38
-        off[1] = inv[1] < 0.0 ? 8u : 0u;
-        off[2] = inv[2] < 0.0 ? 8u : 0u;
         dd = dot(r.d, r.d);
-        reset();
-        const uint32_t root = sc.root_ref;
-        if ((root & REF_LEAF) && !(root & REF_GATED)) {
-            // a one-shape world: bare leaf, no box (bvh.rs:179-180)
-            park(root);
-        } else {
-            RayPre p;
-            p.inv[0] = inv[0]; p.inv[1] = inv[1]; p.inv[2] = inv[2];
-            p.sgn[0] = off[0] != 0; p.sgn[1] = off[1] != 0; p.sgn[2] = off[2] != 0;
-            p.dd = dd;
-            double e;
-            if (slab_test(&sc.root_box[0][0], r, p, t_min, t_max, &e)) {
-                if (root & REF_LEAF) park(root);
-                else cur = root;
-            }
-        }
+        // a moving sphere's box holds for times inside its own span only
+        cull.set(r, r.time >= sc.time_lo && r.time <= sc.time_hi);
+        careful = false;
+        start(sc, t_min, t_max);
     }
 
-    __device__ __forceinline__ void node_step(const DScene& sc, const TraverseLds& lds, StackT* __restrict__ stack, uint32_t tid,
-                                              double t_min, double t_max) {
+    // The reference's slab test (aabb.rs:24-51) on every gate of shape `prim`.
+    __device__ __forceinline__ bool gates_pass(const DScene& sc, uint32_t prim, double t_min, double t_max) const {
+        uint32_t g = sc.gate_of[prim];
+        if (g == NO_GATE) return true;
+        const RayPre p = ray_pre(r);
+        bool ok = true;
+        do {
+            const DGate* __restrict__ gate = sc.gates + g;
+            double e;
+            ok = slab_test(&gate->box[0][0], r, p, t_min, t_max, &e);
+            g = gate->next;
+        } while (ok && g != NO_GATE);
+        return ok;
+    }
+    // After finished(): is `best` the reference's answer?
+    __device__ __forceinline__ bool confirm(const DScene& sc, double t_min, double t_max) const {
+        return careful || best.prim < 0 || gates_pass(sc, (uint32_t)best.prim, t_min, t_max);
+    }
+    __device__ __forceinline__ void begin_careful(const DScene& sc, double t_min, double t_max) {
+        careful = true;
+        start(sc, t_min, t_max);
+    }
+
+    __device__ __forceinline__ void node_step(const DScene& sc, const TraverseLds& lds, StackT* __restrict__ stack, uint32_t tid) {
         uint32_t c0, c1;
-        double e0, e1;
+        float e0, e1;
         bool pass0, pass1;
         if (NODES_IN_LDS) {
-            // thirteen 8-byte reads of one node, issued back to back, one wait
+            // seven 8-byte reads of one node, issued back to back, one wait
             // (LDS byte address = the low half of the generic address of an LDS object)
             const uint32_t node = (uint32_t)(size_t)lds.nodes + cur * NODE_LDS_BYTES;
-            const uint32_t ax = node + off[0], bx = node + (off[0] ^ 8u);
-            const uint32_t ay = node + off[1], by = node + (off[1] ^ 8u);
-            const uint32_t az = node + off[2], bz = node + (off[2] ^ 8u);
-            const uint2 refs = lds_read_u32x2<96>(node);
-            const double l0x = lds_read_f64<0>(ax), h0x = lds_read_f64<0>(bx);
-            const double l0y = lds_read_f64<16>(ay), h0y = lds_read_f64<16>(by);
-            const double l0z = lds_read_f64<32>(az), h0z = lds_read_f64<32>(bz);
-            const double l1x = lds_read_f64<48>(ax), h1x = lds_read_f64<48>(bx);
-            const double l1y = lds_read_f64<64>(ay), h1y = lds_read_f64<64>(by);
-            const double l1z = lds_read_f64<80>(az), h1z = lds_read_f64<80>(bz);
+            const uint32_t ax = node + cull.off[0], bx = node + (cull.off[0] ^ 8u);
+            const uint32_t ay = node + cull.off[1], by = node + (cull.off[1] ^ 8u);
+            const uint32_t az = node + cull.off[2], bz = node + (cull.off[2] ^ 8u);
+            const uint2 refs = lds_read_u32x2<48>(node);
+            const f32x2 nx = lds_read_f32x2<0>(ax), fx = lds_read_f32x2<0>(bx);
+            const f32x2 ny = lds_read_f32x2<16>(ay), fy = lds_read_f32x2<16>(by);
+            const f32x2 nz = lds_read_f32x2<32>(az), fz = lds_read_f32x2<32>(bz);
             lds_wait();
             c0 = refs.x;
             c1 = refs.y;
-            pass0 = slab_near_far(l0x, h0x, l0y, h0y, l0z, h0z, r, inv, t_min, t_max, &e0);
-            pass1 = slab_near_far(l1x, h1x, l1y, h1y, l1z, h1z, r, inv, t_min, t_max, &e1);
+            slab_pair(nx, fx, ny, fy, nz, fz, cull, t_lo, t_hi, &e0, &e1, &pass0, &pass1);
         } else {
             const char* node = reinterpret_cast<const char*>(sc.nodes + cur);
-            c0 = *reinterpret_cast<const uint32_t*>(node + 96);
-            c1 = *reinterpret_cast<const uint32_t*>(node + 100);
-            pass0 = slab_by_address(node, 0, r, inv, off, t_min, t_max, &e0);
-            pass1 = slab_by_address(node, 1, r, inv, off, t_min, t_max, &e1);
+            const uint2 refs = *reinterpret_cast<const uint2*>(node + 48);
+            const f32x2 nx = *reinterpret_cast<const f32x2*>(node + cull.off[0]);
+            const f32x2 fx = *reinterpret_cast<const f32x2*>(node + (cull.off[0] ^ 8u));
+            const f32x2 ny = *reinterpret_cast<const f32x2*>(node + 16 + cull.off[1]);
+            const f32x2 fy = *reinterpret_cast<const f32x2*>(node + 16 + (cull.off[1] ^ 8u));
+            const f32x2 nz = *reinterpret_cast<const f32x2*>(node + 32 + cull.off[2]);
+            const f32x2 fz = *reinterpret_cast<const f32x2*>(node + 32 + (cull.off[2] ^ 8u));
+            c0 = refs.x;
+            c1 = refs.y;
+            slab_pair(nx, fx, ny, fy, nz, fz, cull, t_lo, t_hi, &e0, &e1, &pass0, &pass1);
         }
-        // nothing entered farther than the best hit (plus margin) can beat it
-        const bool near0 = !(e0 > limit), near1 = !(e1 > limit);
         const bool leaf0 = (c0 & REF_LEAF) != 0, leaf1 = (c1 & REF_LEAF) != 0;
-        // a gated leaf is tested iff its box passes; an ungated one whatever its box says
-        if (leaf0 && near0 && (pass0 || !(c0 & REF_GATED))) park(c0);
-        if (leaf1 && near1 && (pass1 || !(c1 & REF_GATED))) park(c1);
-        const bool go0 = pass0 && near0 && !leaf0;
-        const bool go1 = pass1 && near1 && !leaf1;
+        if (pass0 && leaf0) park(c0);
+        if (pass1 && leaf1) park(c1);
+        const bool go0 = pass0 && !leaf0;
+        const bool go1 = pass1 && !leaf1;
         if (go0 && go1) {
             const bool first0 = e0 <= e1;
             stack[sp * BLOCK + tid] = (StackT)(first0 ? c1 : c0);
@@ -266,8 +301,6 @@ struct RayWalk {
     __device__ __forceinline__ void leaf_step(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
         const uint32_t entry = q0;
         q0 = q1;
-        q1 = q2;
-        q2 = q3;
         --nq;
         const uint32_t index = entry & REF_INDEX_MASK;
         const uint32_t tk = entry >> Q_KIND_SHIFT;
@@ -278,8 +311,10 @@ struct RayWalk {
         if (tshape_hit(p, tk, r, dd, t_min, t_max, &t, &side)) {
             // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74)
             if (best.prim < 0 || t < best.t || (t == best.t && (int32_t)index > best.prim)) {
-                best = HitRec{t, (int32_t)index, side};
-                limit = t + fabs(t) * PRUNE_REL;
+                if (!careful || gates_pass(sc, index, t_min, t_max)) {
+                    best = HitRec{t, (int32_t)index, side};
+                    t_hi = fminf(t_hi, f32_not_below(t));
+                }
             }
         }
     }
@@ -366,8 +401,12 @@ __device__ __forceinline__ void traverse_persistent(const DScene& sc, Io& io, ui
         const unsigned long long t0 = now();
         // finished rays leave at once
         if (active && walk.finished()) {
-            io.store(i, cookie, walk.best);
-            active = false;
+            if (walk.confirm(sc, t_min, t_max)) {
+                io.store(i, cookie, walk.best);
+                active = false;
+            } else {
+                walk.begin_careful(sc, t_min, t_max);  // rare: the winner's gate failed
+            }
         }
         const int n_node = __popcll(__ballot(active && walk.wants_node()));
         const int n_leaf = __popcll(__ballot(active && walk.wants_leaf()));
@@ -413,7 +452,7 @@ __device__ __forceinline__ void traverse_persistent(const DScene& sc, Io& io, ui
                     st[STAT_NODE_ITERS] += 1;
                     st[STAT_NODE_LANES] += n_now;
                 }
-                if (active && walk.wants_node()) walk.node_step(sc, lds, stack, tid, t_min, t_max);
+                if (active && walk.wants_node()) walk.node_step(sc, lds, stack, tid);
                 n_now = __popcll(__ballot(active && walk.wants_node()));
             } while (n_now >= enough);
             if (STATS && leader()) st[STAT_CYC_NODE] += now() - t1;
@@ -425,27 +464,6 @@ __device__ __forceinline__ void traverse_persistent(const DScene& sc, Io& io, ui
             unsigned long long v = st[k];
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             if (lane == 0) atomicAdd(stats + k, v);
-        }
-    }
-}
-
-// The same walk for ONE ray per lane, all lanes of the wave at once, no queue: the wave
-// alternates node visits and shape tests, whichever more lanes are waiting for, until
-// every lane with `have` set has its closest hit in walk.best.
-template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS>
-__device__ __forceinline__ void traverse_wave(const DScene& sc, bool have, const RayD& ray, double t_min, double t_max,
-                                              TraverseLds lds, StackT* __restrict__ stack, uint32_t tid,
-                                              RayWalk<BLOCK, StackT, NODES_IN_LDS, SHAPES_IN_LDS>& walk) {
-    walk.reset();
-    if (have) walk.begin(sc, ray, t_min, t_max);
-    for (;;) {
-        const bool wn = have && walk.wants_node(), wl = have && walk.wants_leaf();
-        const int n_node = __popcll(__ballot(wn)), n_leaf = __popcll(__ballot(wl));
-        if (n_node + n_leaf == 0) break;
-        if (n_leaf > n_node) {
-            if (wl) walk.leaf_step(sc, lds, t_min, t_max);
-        } else {
-            if (wn) walk.node_step(sc, lds, stack, tid, t_min, t_max);
         }
     }
 }

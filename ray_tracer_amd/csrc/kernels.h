@@ -157,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DScene sc, const mirt_ray* 
 constexpr int TRAV_BLOCK_LDS = 1024;
 constexpr int TRAV_BLOCK_GLOBAL = 512;
 
-// Dynamic LDS: [stack: levels x TBLOCK entries of StackT][nodes: n_nodes x 104 B][shapes: n_shapes x 80 B].
+// Dynamic LDS: [stack: levels x TBLOCK entries of StackT][nodes: n_nodes x 56 B][shapes: n_shapes x 80 B].
 __host__ __device__ inline size_t trav_stack_bytes(uint32_t levels, size_t entry, int tblock) {
     return (((size_t)levels * tblock * entry) + 15) & ~(size_t)15;
 }
@@ -169,14 +169,10 @@ __host__ __device__ inline size_t trav_nodes_bytes(uint32_t n_nodes) {
 template <int NTHREADS, bool NODES, bool SHAPES>
 __device__ __forceinline__ void stage_tree(const DScene& sc, char* lds_nodes, char* lds_shapes) {
     if (NODES) {
-        // the first 26 dwords (boxes + child references) of every 32-dword DNode
         const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.nodes);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
         const uint32_t words = sc.n_nodes * (NODE_LDS_BYTES / 4);
-        for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) {
-            const uint32_t node = w / (NODE_LDS_BYTES / 4), j = w % (NODE_LDS_BYTES / 4);
-            dst[w] = src[node * (sizeof(DNode) / 4) + j];
-        }
+        for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) dst[w] = src[w];
     }
     if (SHAPES) {
         // the ten traversal parameters of every shape, as they lie in DScene::tparams
@@ -672,6 +668,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
         }
         if (n_shade >= shade_at || n_node + n_leaf == 0) {
             PS_START();
+            if (have && walk.finished() && !walk.confirm(sc, rp.t_min, rp.t_max)) walk.begin_careful(sc, rp.t_min, rp.t_max);
             if (have && walk.finished()) {
                 if (bounce != bounce0) ++extra_segments;
                 const HitRec h = walk.best;
@@ -714,7 +711,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
             n_now = n_node;
             do {
                 PS_START();
-                if (have && walk.wants_node()) walk.node_step(sc, lds, stack, tid, rp.t_min, rp.t_max);
+                if (have && walk.wants_node()) walk.node_step(sc, lds, stack, tid);
                 PS_STOP(PS_NODE, n_now);
                 n_now = __popcll(__ballot(have && walk.wants_node()));
             } while (n_now >= enough);

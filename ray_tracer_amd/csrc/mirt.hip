@@ -87,7 +87,6 @@ struct mirt_scene {
     bool has_bvh = false;
     bool has_noise = false;
     int texture_level = 0;      // TextureLevel: the highest texture kind the scene holds
-    bool regrouped = false;     // fast tree = SAH over the reference's leaf groups (else: reference topology)
     int cu_count = 0;
     // One block of device memory a render call left behind for the next one (the per-pass
     // buffers: 2 GB at the default pass size); a call takes it if it is large enough and
@@ -271,10 +270,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     traversal_shapes(desc, &tkinds, &tparams);
     BuiltTree tree;
     if (desc->nodes) {
-        // The regrouped tree needs every Node box to contain its inner children's boxes
-        // (true of any tree BoundingVolumeHierarchy::new builds); otherwise keep the
-        // reference's own topology.
-        tree = boxes_nest(desc) ? regroup(desc, tkinds.data(), MAX_TREE_HEIGHT) : flatten_reference(desc, tkinds.data());
+        tree = build_fast_tree(desc, tkinds.data(), MAX_TREE_HEIGHT);
         if (tree.height > (uint32_t)MAX_TREE_HEIGHT)
             return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", tree.height, MAX_TREE_HEIGHT);
         // the reference-order kernel walks the caller's own members: bound their depth too
@@ -288,7 +284,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
         if (deepest > (uint32_t)MAX_TREE_HEIGHT)
             return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", deepest, MAX_TREE_HEIGHT);
     }
-    const std::vector<DNode>& nodes = tree.nodes;
+    const std::vector<CNode>& nodes = tree.nodes;
     const uint32_t root_ref = tree.root_ref, height = tree.height;
 
     // ---- upload
@@ -324,7 +320,9 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     } while (0)
     DShape* d_shapes = nullptr;
     double* d_tparams = nullptr;
-    DNode* d_nodes = nullptr;
+    CNode* d_nodes = nullptr;
+    DGate* d_gates = nullptr;
+    uint32_t* d_gate_of = nullptr;
     mirt_bvh_member* d_members = nullptr;
     mirt_material* d_materials = nullptr;
     mirt_texture* d_textures = nullptr;
@@ -333,6 +331,8 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     SCENE_TRY(upload(&d_shapes, shapes.data(), shapes.size()));
     SCENE_TRY(upload(&d_tparams, tparams.data(), tparams.size()));
     SCENE_TRY(upload(&d_nodes, nodes.data(), nodes.size()));
+    SCENE_TRY(upload(&d_gates, tree.gates.data(), tree.gates.size()));
+    SCENE_TRY(upload(&d_gate_of, tree.gate_of.data(), tree.gate_of.size()));
     SCENE_TRY(upload(&d_members, desc->nodes, desc->nodes ? desc->n_nodes : 0));
     SCENE_TRY(upload(&d_materials, desc->materials, desc->n_materials));
     SCENE_TRY(upload(&d_textures, desc->textures, desc->n_textures));
@@ -350,6 +350,10 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     sc->d.shapes = d_shapes;
     sc->d.tparams = d_tparams;
     sc->d.nodes = d_nodes;
+    sc->d.gates = d_gates;
+    sc->d.gate_of = d_gate_of;
+    sc->d.time_lo = tree.time_lo;
+    sc->d.time_hi = tree.time_hi;
     sc->d.members = d_members;
     sc->d.materials = d_materials;
     sc->d.textures = d_textures;
@@ -359,8 +363,6 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     sc->d.n_members = desc->nodes ? desc->n_nodes : 0;
     sc->d.n_nodes = (uint32_t)nodes.size();
     sc->d.root_ref = root_ref;
-    std::memcpy(sc->d.root_box, tree.root_box, sizeof tree.root_box);
-    sc->regrouped = tree.regrouped;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) sc->cu_count = prop.multiProcessorCount;
     if (sc->cu_count <= 0) sc->cu_count = 256;
