@@ -51,13 +51,26 @@ MIRT_HD uint64_t mirt_rng_bits(uint64_t stream, uint32_t stage, uint32_t k) {
     return mirt_mix64(stream + MIRT_GOLDEN * (ctr + 1u));
 }
 
-/* Uniform double in [0, 1) with 53 random bits. */
+/* Uniform double in [0, 1) with 53 random bits (host-side set-up draws). */
 MIRT_HD double mirt_bits_to_double(uint64_t bits) {
     return (double)(bits >> 11) * 0x1.0p-53;
 }
 
+/* Uniform double in [1, 2): 52 random bits as the mantissa under the exponent of 1.0.
+ * rand 0.7.3 builds gen_range(0.0, 1.0) the same way (a [1, 2) value from 52 bits, then
+ * value * 1.0 + (0.0 - 1.0)); on the device it is one integer instruction. */
+MIRT_HD double mirt_bits_to_1_2(uint64_t bits) {
+    union {
+        uint64_t u;
+        double d;
+    } v;
+    v.u = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    return v.d;
+}
+
+/* random_double() of the render path (src/util.rs:8-10): uniform in [0, 1), 52 random bits. */
 MIRT_HD double mirt_rng_double(uint64_t stream, uint32_t stage, uint32_t k) {
-    return mirt_bits_to_double(mirt_rng_bits(stream, stage, k));
+    return mirt_bits_to_1_2(mirt_rng_bits(stream, stage, k)) - 1.0;
 }
 
 /* ---- sequential generator for host-side set-up ------------------------- */

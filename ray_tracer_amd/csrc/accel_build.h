@@ -76,8 +76,8 @@ inline double half_area(const Box& b) {
     return std::isfinite(a) ? a : std::numeric_limits<double>::max();
 }
 
-// `tk` = TraverseKind of every shape (how the fast traversal tests it).
-inline uint32_t leaf_ref(const uint32_t* tk, uint32_t shape) { return REF_LEAF | (tk[shape] << REF_KIND_SHIFT) | shape; }
+// `tk` = TraverseKind << REF_KIND_SHIFT | ShadeClass << REF_CLASS_SHIFT of every shape.
+inline uint32_t leaf_ref(const uint32_t* tk, uint32_t shape) { return REF_LEAF | tk[shape] | shape; }
 
 // Bounding box of the points at which Shape::hit can report a hit (src/hittable.rs:105-137,
 // 185-207, 249-271, 313-335, 432-445, 487-521), whatever the sign of a radius or the order
@@ -146,21 +146,22 @@ inline void put_box(CNode& n, int c, const Box& b) {
 
 }  // namespace accel
 
-// TraverseKind and the ten traversal parameters of every shape (device_scene.h).
-inline void traversal_shapes(const mirt_scene_desc* desc, std::vector<uint32_t>* tk, std::vector<double>* params) {
+// TraverseKind and the traversal parameters (ShapeRec::f) of every shape.
+inline void traversal_shapes(const mirt_scene_desc* desc, std::vector<uint32_t>* tk, std::vector<ShapeRec>* recs) {
     tk->resize(desc->n_shapes);
-    params->assign((size_t)desc->n_shapes * TPARAMS_PER_SHAPE, 0.0);
+    recs->resize(desc->n_shapes);
     for (uint32_t i = 0; i < desc->n_shapes; ++i) {
         const mirt_shape& s = desc->shapes[i];
-        double* p = params->data() + (size_t)i * TPARAMS_PER_SHAPE;
-        std::memcpy(p, s.f, sizeof s.f);
+        ShapeRec& rec = (*recs)[i];
+        std::memset(&rec, 0, sizeof rec);
+        double* p = rec.f;
+        std::memcpy(p, s.f, sizeof rec.f);
         (*tk)[i] = s.kind;
         if (s.kind == MIRT_SHAPE_SPHERE) {
             (*tk)[i] = TK_SPHERE;
             p[4] = p[5] = p[6] = 0.0;  // c1 - c0
             p[7] = 0.0;                // ts
             p[8] = 1.0;                // 1 / (te - ts)
-            p[9] = 0.0;
         } else if (s.kind == MIRT_SHAPE_MOVING_SPHERE) {
             const double movement_time = s.f[8] - s.f[7];  // hittable.rs:556
             int exp = 0;
@@ -171,10 +172,49 @@ inline void traversal_shapes(const mirt_scene_desc* desc, std::vector<uint32_t>*
                 for (int a = 0; a < 3; ++a) p[4 + a] = s.f[4 + a] - s.f[a];  // hittable.rs:558
                 p[7] = s.f[7];
                 p[8] = 1.0 / movement_time;  // exact
-                p[9] = 0.0;
             } else {
                 (*tk)[i] = TK_MOVING_SPHERE;
             }
+        }
+    }
+}
+
+// What shading a hit needs, folded into the shapes' records: the material's constants, and for a
+// texture that is not a constant its index in a table that holds only such textures and what
+// they lead to (a scene has one constant texture per plain sphere; none of them is in it).
+inline void shading_records(const mirt_scene_desc* desc, std::vector<ShapeRec>* recs, std::vector<mirt_texture>* table) {
+    std::vector<uint8_t> wanted(desc->n_textures, 0);
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        const mirt_material& m = desc->materials[desc->shapes[i].material];
+        if ((m.kind == MIRT_MAT_LAMBERTIAN || m.kind == MIRT_MAT_DIFFUSE_LIGHT) && desc->textures[m.texture].kind != MIRT_TEX_CONSTANT)
+            wanted[m.texture] = 1;
+    }
+    // children carry smaller indices than their parent (validated): one sweep from the top
+    for (uint32_t t = desc->n_textures; t-- > 0;)
+        if (wanted[t] && desc->textures[t].kind == MIRT_TEX_CHECKER) wanted[desc->textures[t].even] = wanted[desc->textures[t].odd] = 1;
+    std::vector<uint32_t> place(desc->n_textures, NO_TEXTURE);
+    for (uint32_t t = 0; t < desc->n_textures; ++t) {
+        if (!wanted[t]) continue;
+        mirt_texture copy = desc->textures[t];
+        if (copy.kind == MIRT_TEX_CHECKER) {
+            copy.even = place[copy.even];
+            copy.odd = place[copy.odd];
+        }
+        place[t] = (uint32_t)table->size();
+        table->push_back(copy);
+    }
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        ShapeRec& rec = (*recs)[i];
+        const mirt_material& m = desc->materials[desc->shapes[i].material];
+        rec.material = desc->shapes[i].material;
+        rec.texture = NO_TEXTURE;
+        rec.param = m.param;
+        if (m.kind == MIRT_MAT_LAMBERTIAN || m.kind == MIRT_MAT_DIFFUSE_LIGHT) {
+            const mirt_texture& tex = desc->textures[m.texture];
+            if (tex.kind == MIRT_TEX_CONSTANT) std::memcpy(rec.color, tex.color, sizeof rec.color);
+            else rec.texture = place[m.texture];
+        } else {
+            std::memcpy(rec.color, m.albedo, sizeof rec.color);
         }
     }
 }
@@ -228,6 +268,44 @@ inline void build_gates(const mirt_scene_desc* desc, BuiltTree* t) {
                 cg.next = nest ? NO_GATE : gate_index[i];
                 t->gates.push_back(cg);
             }
+        }
+    }
+}
+
+// ShapeRec::sure of every shape: its gate's box moved inward by what the f32 test of
+// RayWalk::confirm may err by (2^-19 of each bound's magnitude, as the culling boxes move
+// outward), then to the next f32 inward.  A shape without a gate gets a box no ray misses; a
+// shape whose gate leads on to further gates (boxes that do not nest) or whose gate is too thin
+// gets one no ray is sure to cross, and the exact test decides.
+inline void sure_boxes(const BuiltTree& t, std::vector<ShapeRec>* recs) {
+    using namespace accel;
+    const float big = std::numeric_limits<float>::max();
+    for (size_t i = 0; i < recs->size(); ++i) {
+        ShapeRec& rec = (*recs)[i];
+        const uint32_t g = t.gate_of[i];
+        for (int a = 0; a < 3; ++a) {
+            if (g == NO_GATE) {
+                rec.sure[a][0] = -big;
+                rec.sure[a][1] = big;
+                continue;
+            }
+            const DGate& gate = t.gates[g];
+            const double lo = gate.box[a][0], hi = gate.box[a][1];
+            const double size = hi - lo;
+            const bool usable = gate.next == NO_GATE && std::isfinite(lo) && std::isfinite(hi) && size > 0.0 &&
+                                std::fabs(lo) < 0x1.0p40 && std::fabs(hi) < 0x1.0p40;
+            float l = big, h = -big;
+            if (usable) {
+                const double slack = 1.0e-6 * size + 1.0e-30;
+                l = f32_above(lo + (std::fabs(lo) * CULL_REL + slack));
+                h = f32_below(hi - (std::fabs(hi) * CULL_REL + slack));
+                if (!(l < h)) {
+                    l = big;
+                    h = -big;
+                }
+            }
+            rec.sure[a][0] = l;
+            rec.sure[a][1] = h;
         }
     }
 }
@@ -316,6 +394,7 @@ struct Builder {
 }  // namespace accel
 
 // Gates from the reference's tree, culling tree over the shapes' own boxes.
+// `tk`: per shape, TraverseKind << REF_KIND_SHIFT | ShadeClass << REF_CLASS_SHIFT.
 inline BuiltTree build_fast_tree(const mirt_scene_desc* desc, const uint32_t* tk, uint32_t max_height) {
     using namespace accel;
     BuiltTree t;

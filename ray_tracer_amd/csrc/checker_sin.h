@@ -62,4 +62,24 @@ CHECKER_SIN_HD double sin_small(double x) {
     return (n & 2) ? -v : v;
 }
 
+// The checker texture only asks whether sin(10x) * sin(10y) * sin(10z) is negative
+// (texture.rs:45-54), and the sign of a sine needs no polynomial: with n = rint(x * 2/pi) and
+// r = x - n * pi/2, sin(x) has the sign of r for n = 0 (mod 4), is positive for n = 1, has the
+// opposite sign of r for n = 2 and is negative for n = 3 (|r| <= pi/4 + a little).  Two terms
+// of pi/2 give r to within 3e-15 for |x| < 2^20 * pi/2 (n * pio2_1 is exact, the third piece
+// of pi/2 is below 2.1e-21), so the sign of r is certain once |r| > 1e-12.
+// Returns 1 (negative sine), 0 (positive sine) or -1: not decided here (|x| too large or not
+// finite, or x within 1e-12 of a multiple of pi/2 -- there the caller evaluates the sine).
+CHECKER_SIN_HD int sin_is_negative_fast(double x) {
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_2 = 6.07710050630396597660e-11;
+    if (!(__builtin_fabs(x) < SIN_SMALL_LIMIT)) return -1;
+    const double fn = __builtin_rint(x * invpio2);
+    const int n = (int)fn;
+    const double r = (x - fn * pio2_1) - fn * pio2_2;
+    if (!(__builtin_fabs(r) > 1.0e-12)) return -1;
+    const int flipped = (n >> 1) & 1;
+    return (n & 1) ? flipped : (flipped ^ (r < 0.0 ? 1 : 0));
+}
+
 }  // namespace mirt

@@ -12,9 +12,11 @@ namespace mirt {
 //   bit 31      : 1 = leaf (one shape), 0 = inner node
 //   inner node  : bits 0..30 = index into the CNode array
 //   leaf        : bits 26..28 = TraverseKind of the shape
+//                 bits 23..25 = ShadeClass of its material
 //                 bits 0..22  = index into the sorted shape array
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_KIND_SHIFT = 26;
+constexpr uint32_t REF_CLASS_SHIFT = 23;
 constexpr uint32_t REF_INDEX_MASK = 0x007FFFFFu;
 constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^23 - 1
 
@@ -50,7 +52,7 @@ struct alignas(32) DShape {
     uint32_t kind;      // MIRT_SHAPE_*
     uint32_t material;  // index into materials
     uint32_t cls;       // shade class of its material (SHADE_*), precomputed
-    uint32_t pad;
+    uint32_t tk;        // TraverseKind
 };
 static_assert(sizeof(DShape) == 96, "DShape is 96 bytes");
 
@@ -61,9 +63,6 @@ static_assert(sizeof(DShape) == 96, "DShape is 96 bytes");
 // carries the bits of Moving::center (src/hittable.rs:550-561), and a static sphere is the
 // same formula with c1 - c0 = 0 (c0 + x * 0 = c0 for any finite x).  One code path for
 // every sphere of the usual scenes means no divergence between the two kinds.
-// Parameters of the fast traversal, ten doubles per shape (DScene::tparams):
-//   TK_SPHERE          {c0x, c0y, c0z, radius, c1x - c0x, c1y - c0y, c1z - c0z, ts, 1 / (te - ts)}
-//   every other kind   the shape's own parameters (mirt_shape.f)
 enum TraverseKind : uint32_t {
     TK_SPHERE = 0,
     TK_XY_RECT = 1,
@@ -72,7 +71,29 @@ enum TraverseKind : uint32_t {
     TK_CUBE = 4,
     TK_MOVING_SPHERE = 5  // movement time not a power of two: keeps the division
 };
-constexpr int TPARAMS_PER_SHAPE = 10;
+
+// One record per shape (DScene::recs), everything the path kernel needs to test the shape
+// and to shade a hit on it, so that it reads ONE place (staged in LDS when the scene fits):
+//   f[0..8]    parameters of the fast traversal
+//                TK_SPHERE          {c0x, c0y, c0z, radius, c1x - c0x, c1y - c0y, c1z - c0z, ts, 1 / (te - ts)}
+//                every other kind   the shape's own parameters (mirt_shape.f)
+//   material   index into DScene::materials
+//   texture    lambertian / diffuse light whose texture is not a constant: index into
+//              DScene::shade_textures; NO_TEXTURE otherwise
+//   color      lambertian / diffuse light with a constant texture: its colour; metal: albedo
+//   param      metal: fuzziness; dielectric: refraction index
+//   sure       [axis][lo, hi]: the box of the shape's gate moved INWARD (accel_build.h); a ray that
+//              provably crosses it needs no exact gate test (RayWalk::confirm)
+constexpr uint32_t NO_TEXTURE = 0xFFFFFFFFu;
+struct alignas(8) ShapeRec {
+    double f[9];
+    uint32_t material;
+    uint32_t texture;
+    double color[3];
+    double param;
+    float sure[3][2];
+};
+static_assert(sizeof(ShapeRec) == 136, "ShapeRec is 136 bytes");
 
 // Shade classes: paths are binned by this after each closest-hit query so that a
 // wave of the shade kernel runs one material/texture kind.
@@ -99,7 +120,9 @@ struct DScene {
     const DGate* gates;              // one per BVHMember::Node of the reference's tree
     const uint32_t* gate_of;         // per shape: its first gate, or NO_GATE
     const DShape* shapes;            // BVH-sorted order
-    const double* tparams;           // TPARAMS_PER_SHAPE doubles per shape, see TraverseKind
+    const ShapeRec* recs;            // one per shape, see ShapeRec
+    const mirt_texture* shade_textures;  // the textures ShapeRec::texture can lead to, children before parents
+    uint32_t n_shade_textures;
     const mirt_bvh_member* members;  // the reference's own member array (post-order, root last)
     const mirt_material* materials;
     const mirt_texture* textures;

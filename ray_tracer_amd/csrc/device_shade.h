@@ -26,21 +26,26 @@ struct PathRng {
     uint64_t arg;  // stream + GOLDEN * ((stage << 32 | k) + 1) for the next draw
     __device__ __forceinline__ PathRng(uint64_t stream_, uint32_t stage, uint32_t k)
         : stream(stream_), arg(stream_ + MIRT_GOLDEN * ((((uint64_t)stage << 32) | (uint64_t)k) + 1u)) {}
-    __device__ __forceinline__ double random_double() {  // util.rs:8-10
-        const double x = mirt_bits_to_double(mirt_mix64(arg));
+    // a value of [1, 2): random_double() + 1.0, exactly
+    __device__ __forceinline__ double random_1_2() {
+        const double x = mirt_bits_to_1_2(mirt_mix64(arg));
         arg += MIRT_GOLDEN;
         return x;
     }
+    __device__ __forceinline__ double random_double() { return random_1_2() - 1.0; }  // util.rs:8-10
+    // random_double() * 2.0 - 1.0 (camera.rs:81, material.rs:214-216 after vec3 arithmetic): with
+    // x = random_double() + 1.0 that is 2x - 3, and x - 1, 2(x - 1) and 2(x - 1) - 1 are all
+    // exact in f64 (multiples of 2^-51 below 2 in magnitude), so one fused operation gives the
+    // same bits as the reference's three roundings
+    __device__ __forceinline__ double random_pm1() { return __builtin_fma(random_1_2(), 2.0, -3.0); }
 };
 
 // camera.rs:78-88
 __device__ __forceinline__ void random_in_unit_disk(PathRng& rng, double* x, double* y) {
     double px, py;
     do {
-        double a = rng.random_double();
-        double b = rng.random_double();
-        px = a * 2.0 - 1.0;
-        py = b * 2.0 - 1.0;
+        px = rng.random_pm1();
+        py = rng.random_pm1();
     } while (px * px + py * py + 0.0 * 0.0 >= 1.0);
     *x = px;
     *y = py;
@@ -74,51 +79,52 @@ struct Surface {
     V3 p;       // ray.point_at(t)
     V3 normal;  // flipped against the ray, hittable.rs:36-41
     bool front_facing;
-    uint32_t material;
     // what sphere_uv / the rect u,v need, computed on demand by surface_uv()
     V3 outward_normal;
-    uint32_t kind;
+    uint32_t kind;  // TraverseKind of the surface (a cube's side: that of its rect)
     double ua, ub, a0, a1, b0, b1;  // rects: in-plane hit coordinates and extents
 };
 
-// Rebuilds what Hit::new stored for the closest hit {t, prim, side} of ray r.
-__device__ __forceinline__ Surface surface_at(const DScene& sc, const RayD& r, double t, uint32_t prim, int side) {
-    const DShape* __restrict__ s = sc.shapes + prim;
-    const double* __restrict__ f = s->f;
+// Rebuilds what Hit::new stored for the closest hit {t, side} of ray r on a shape given by
+// its TraverseKind and traversal parameters (device_scene.h; global memory or LDS).
+__device__ __forceinline__ Surface surface_at(const RayD& r, double t, uint32_t tk, const double* __restrict__ f, int side) {
     Surface h;
-    h.material = s->material;
-    h.kind = s->kind;
     h.p = r.o + t * r.d;  // ray.rs:31-33
-    h.ua = h.ub = h.a0 = h.a1 = h.b0 = h.b1 = 0.0;
-    uint32_t kind = s->kind;
+    h.ua = h.ub = 0.0;
+    uint32_t kind = tk;
     double a0 = f[0], a1 = f[1], b0 = f[2], b1 = f[3];
-    if (kind == MIRT_SHAPE_CUBE) {
+    if (tk == TK_CUBE) {
         // side -> the rect Cube::new built for it (hittable.rs:405-412)
         const double p0x = f[0], p0y = f[1], p0z = f[2], p1x = f[3], p1y = f[4], p1z = f[5];
         if (side < 2) {
-            kind = MIRT_SHAPE_XY_RECT; a0 = p0x; a1 = p1x; b0 = p0y; b1 = p1y;
+            kind = TK_XY_RECT; a0 = p0x; a1 = p1x; b0 = p0y; b1 = p1y;
         } else if (side < 4) {
-            kind = MIRT_SHAPE_XZ_RECT; a0 = p0x; a1 = p1x; b0 = p0z; b1 = p1z;
+            kind = TK_XZ_RECT; a0 = p0x; a1 = p1x; b0 = p0z; b1 = p1z;
         } else {
-            kind = MIRT_SHAPE_YZ_RECT; a0 = p0y; a1 = p1y; b0 = p0z; b1 = p1z;
+            kind = TK_YZ_RECT; a0 = p0y; a1 = p1y; b0 = p0z; b1 = p1z;
         }
     }
     switch (kind) {
-        case MIRT_SHAPE_SPHERE:
-            h.outward_normal = (h.p - v3(f[0], f[1], f[2])) / f[3];  // hittable.rs:130
+        case TK_SPHERE: {
+            // hittable.rs:130 and 514; the centre as tshape_hit computes it (Moving::center with
+            // the division by a power of two as a multiplication; a static sphere moves by zero)
+            const double frac = (r.time - f[7]) * f[8];
+            const V3 c = v3(f[0], f[1], f[2]) + frac * v3(f[4], f[5], f[6]);
+            h.outward_normal = (h.p - c) / f[3];
             break;
-        case MIRT_SHAPE_MOVING_SPHERE:
+        }
+        case TK_MOVING_SPHERE:
             h.outward_normal = (h.p - moving_center(f, r.time)) / f[3];  // hittable.rs:514
             break;
-        case MIRT_SHAPE_XY_RECT:
+        case TK_XY_RECT:
             h.outward_normal = v3(0.0, 0.0, 1.0);
             h.ua = r.o.x + t * r.d.x; h.ub = r.o.y + t * r.d.y;
             break;
-        case MIRT_SHAPE_XZ_RECT:
+        case TK_XZ_RECT:
             h.outward_normal = v3(0.0, 1.0, 0.0);
             h.ua = r.o.x + t * r.d.x; h.ub = r.o.z + t * r.d.z;
             break;
-        default:  // MIRT_SHAPE_YZ_RECT
+        default:  // TK_YZ_RECT
             h.outward_normal = v3(1.0, 0.0, 0.0);
             h.ua = r.o.y + t * r.d.y; h.ub = r.o.z + t * r.d.z;
             break;
@@ -132,7 +138,7 @@ __device__ __forceinline__ Surface surface_at(const DScene& sc, const RayD& r, d
 
 // Hit::u(), Hit::v(): only image textures read them, so they are computed only there.
 __device__ __forceinline__ void surface_uv(const Surface& h, double* u, double* v) {
-    if (h.kind == MIRT_SHAPE_SPHERE || h.kind == MIRT_SHAPE_MOVING_SPHERE) {
+    if (h.kind == TK_SPHERE || h.kind == TK_MOVING_SPHERE) {
         // sphere_uv, hittable.rs:732-749
         const double PI = 3.14159265358979323846264338327950288;
         const double TAU = 6.28318530717958647692528676655900577;
@@ -219,6 +225,21 @@ __device__ __forceinline__ double perlin_turbulence(const double* __restrict__ v
 // for the rest.
 __device__ __noinline__ double sin_rare(double x) { return sin(x); }
 __device__ __forceinline__ double checker_sin(double x) { return fabs(x) < SIN_SMALL_LIMIT ? sin_small(x) : sin_rare(x); }
+// texture.rs:47-49 evaluated in full: `sines < 0.0`
+__device__ __noinline__ bool checker_odd_slow(double x, double y, double z) {
+    const double sines = checker_sin(10.0 * x) * checker_sin(10.0 * y) * checker_sin(10.0 * z);
+    return sines < 0.0;
+}
+// The same decision from the signs of the three sines where each is certain (a product of
+// three sines of magnitude > 1e-13 neither vanishes nor underflows, and is negative iff an odd
+// number of factors is); the full evaluation otherwise.
+__device__ __forceinline__ bool checker_odd(const V3& p) {
+    const int sx = sin_is_negative_fast(10.0 * p.x);
+    const int sy = sin_is_negative_fast(10.0 * p.y);
+    const int sz = sin_is_negative_fast(10.0 * p.z);
+    if ((sx | sy | sz) < 0) return checker_odd_slow(p.x, p.y, p.z);
+    return ((sx ^ sy ^ sz) & 1) != 0;
+}
 
 // texture.rs:195-205
 __device__ __forceinline__ double fclamp(double x, double lo, double hi) {
@@ -233,25 +254,20 @@ __device__ __forceinline__ double fclamp(double x, double lo, double hi) {
 // noise or image texture runs a kernel that holds more waves per SIMD.
 enum TextureLevel : int { TEXTURES_CONSTANT = 0, TEXTURES_CHECKER = 1, TEXTURES_IMAGE = 2, TEXTURES_ALL = 3, N_TEXTURE_LEVELS = 4 };
 
-// Texture::value (texture.rs:184-193).  Checker nesting is followed iteratively.
+// Texture::value (texture.rs:184-193) of entry `tex` of `textures` (DScene::shade_textures, or
+// its copy in LDS).  Checker nesting is followed iteratively.
 // `lds_tables` = the scene's first `n_staged` Perlin tables as the shade kernel staged them
 // in LDS (null / 0 when it staged none); other tables are read from global memory.
 // A texture of a kind above LEVEL evaluates to black: the host picks LEVEL from the scene.
 template <int LEVEL>
-__device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, const Surface& h,
+__device__ __forceinline__ V3 texture_value(const DScene& sc, const mirt_texture* textures, uint32_t tex, const Surface& h,
                                             const mirt_perlin* lds_tables, uint32_t n_staged) {
     for (int guard = 0; guard < 64; ++guard) {
-        const mirt_texture* __restrict__ t = sc.textures + tex;
+        const mirt_texture* t = textures + tex;
         const uint32_t kind = t->kind;
         if (kind == MIRT_TEX_CONSTANT) return v3(t->color[0], t->color[1], t->color[2]);
         if (LEVEL >= TEXTURES_CHECKER && kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
-            // one sine at a time (side by side the scheduler would hold all three in registers)
-            double sines = checker_sin(10.0 * h.p.x);
-            __builtin_amdgcn_sched_barrier(0);
-            sines = sines * checker_sin(10.0 * h.p.y);
-            __builtin_amdgcn_sched_barrier(0);
-            sines = sines * checker_sin(10.0 * h.p.z);
-            tex = (sines < 0.0) ? t->odd : t->even;
+            tex = checker_odd(h.p) ? t->odd : t->even;
             continue;
         }
         if (LEVEL >= TEXTURES_ALL && kind == MIRT_TEX_NOISE) {  // texture.rs:82-87
@@ -290,10 +306,10 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, uint32_t tex, cons
 __device__ __forceinline__ V3 random_in_unit_sphere(PathRng& rng) {
     V3 p;
     do {
-        double a = rng.random_double();
-        double b = rng.random_double();
-        double c = rng.random_double();
-        p = v3(a * 2.0 - 1.0, b * 2.0 - 1.0, c * 2.0 - 1.0);
+        const double a = rng.random_pm1();
+        const double b = rng.random_pm1();
+        const double c = rng.random_pm1();
+        p = v3(a, b, c);
     } while (square_length(p) >= 1.0);
     return p;
 }

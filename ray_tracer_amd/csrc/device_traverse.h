@@ -40,7 +40,7 @@ __device__ __forceinline__ uint32_t mbcnt_lt(unsigned long long mask) {
 
 constexpr uint32_t CUR_DONE = 0x7FFFFFFFu;
 constexpr int NODE_LDS_BYTES = sizeof(CNode);  // 56
-constexpr int SHAPE_LDS_BYTES = 80;            // DShape::f
+constexpr int SHAPE_LDS_BYTES = sizeof(ShapeRec);  // 136
 constexpr uint32_t TUNING_DEFAULT = 2u | (64u << 8);  // see traverse_persistent
 constexpr uint32_t CHUNK_RAYS = 512;  // most rays a wave takes from the queue per fetch
 
@@ -98,7 +98,7 @@ enum TraverseStat : int {
 // Where the tree and the shapes are read from.
 struct TraverseLds {
     const char* nodes;   // NODE_LDS_BYTES apart, or nullptr: read DScene::nodes
-    const char* shapes;  // SHAPE_LDS_BYTES apart, or nullptr: read DScene::tparams
+    const char* shapes;  // SHAPE_LDS_BYTES apart, or nullptr: read DScene::recs
 };
 
 // The culling slab test, f32, for the two children of a node at once.
@@ -116,18 +116,39 @@ struct TraverseLds {
 struct CullRay {
     float inv[3], c_near[3], c_far[3];
     uint32_t off[3];  // 8 if the ray runs down the axis (near bound = upper) else 0
+    // every term finite and far from the ends of f32's range: the same constants then also
+    // bound t from the other side (sure_to_cross)
+    bool tame;
     __device__ __forceinline__ void set(const RayD& r, bool cull) {
         const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+        float size = 0.0f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float i32 = __builtin_amdgcn_rcpf((float)d[a]);
             const float p = (float)o[a] * i32;
             const float e = __builtin_fabsf(p) * 0x1.0p-19f;
+            size += __builtin_fabsf(i32) + __builtin_fabsf(p);
             inv[a] = cull ? i32 : 0.0f;
             c_near[a] = cull ? -p - e : -__builtin_inff();
             c_far[a] = cull ? -p + e : __builtin_inff();
             off[a] = i32 < 0.0f ? 8u : 0u;
         }
+        tame = cull && size < 1.0e18f;  // false for a NaN
+    }
+    // Does the ray cross `box` ([axis][lo, hi], f32, already moved inward by the host) somewhere
+    // in (t_lo, t_hi), beyond what rounding could undo?  The mirror image of slab_pair: the near
+    // bound with the FAR constant bounds the entry from above, the far bound with the NEAR
+    // constant the exit from below.  Only for a tame ray (no NaN can arise, none is dropped).
+    __device__ __forceinline__ bool sure_to_cross(const float* __restrict__ box, float t_lo, float t_hi) const {
+        float in = t_lo, out = t_hi;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = box[2 * a], hi = box[2 * a + 1];
+            const float near = off[a] ? hi : lo, far = off[a] ? lo : hi;
+            in = fmaxf(in, __builtin_fmaf(near, inv[a], c_far[a]));
+            out = fminf(out, __builtin_fmaf(far, inv[a], c_near[a]));
+        }
+        return tame && out > in;
     }
 };
 
@@ -155,6 +176,28 @@ __device__ __forceinline__ void slab_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32x2 fy
 __device__ __forceinline__ float f32_not_below(double x) { return (float)(x + fabs(x) * 2.0e-6); }
 __device__ __forceinline__ float f32_not_above(double x) { return (float)(x - fabs(x) * 2.0e-6); }
 
+// The reference's slab test (aabb.rs:24-51) on every gate of shape `prim`.  Rarely needed: a
+// call, so that its registers are not the kernels'.
+// (The ray travels by value: a reference would pin the caller's copy to memory.)
+__device__ __noinline__ bool gates_pass(const DGate* __restrict__ gates, const uint32_t* __restrict__ gate_of, uint32_t prim,
+                                        double ox, double oy, double oz, double dx, double dy, double dz, double t_min, double t_max) {
+    uint32_t g = gate_of[prim];
+    if (g == NO_GATE) return true;
+    RayD r;
+    r.o = v3(ox, oy, oz);
+    r.d = v3(dx, dy, dz);
+    r.time = 0.0;
+    const RayPre p = ray_pre(r);
+    bool ok = true;
+    do {
+        const DGate* __restrict__ gate = gates + g;
+        double e;
+        ok = slab_test(&gate->box[0][0], r, p, t_min, t_max, &e);
+        g = gate->next;
+    } while (ok && g != NO_GATE);
+    return ok;
+}
+
 // The walk of ONE ray (one lane) through the tree, cut into steps so that a wave can
 // choose, trip by trip, which step to run for which lanes:
 //   begin(ray)            per-ray constants of the culling test, root
@@ -167,7 +210,9 @@ __device__ __forceinline__ float f32_not_above(double x) { return (float)(x - fa
 // stack: LDS, [level][BLOCK] entries of StackT, this lane's column is `tid`.
 template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS>
 struct RayWalk {
-    static constexpr uint32_t Q_KIND_SHIFT = 26;
+    // best.side of a hit found by a walk: cube side | ShadeClass << 4 | TraverseKind << 7
+    // (bits 23..28 of the leaf reference, moved down as they are)
+    static constexpr uint32_t SIDE_MASK = 15u, CLASS_SHIFT = 4, TK_SHIFT = 7;
     RayD r;
     CullRay cull;
     double dd;
@@ -176,8 +221,8 @@ struct RayWalk {
     float t_hi;   // f32 not below min(t_max, best t): nothing entered beyond it can beat the best hit
     uint32_t cur;
     int sp;
-    // shapes parked for the next leaf steps: TraverseKind << 26 | index, at most two (the
-    // two children of one node), kept in registers q0 (next out), q1
+    // shapes parked for the next leaf steps (leaf references), at most two (the two children
+    // of one node), kept in registers q0 (next out), q1
     uint32_t q0, q1, nq;
     bool careful;  // second walk: a hit counts only if its shape's gates pass
 
@@ -195,7 +240,7 @@ struct RayWalk {
 
     __device__ __forceinline__ void park(uint32_t ref) {
         q1 = q0;
-        q0 = (((ref >> REF_KIND_SHIFT) & 7u) << Q_KIND_SHIFT) | (ref & REF_INDEX_MASK);
+        q0 = ref;
         ++nq;
     }
 
@@ -221,23 +266,14 @@ struct RayWalk {
         start(sc, t_min, t_max);
     }
 
-    // The reference's slab test (aabb.rs:24-51) on every gate of shape `prim`.
-    __device__ __forceinline__ bool gates_pass(const DScene& sc, uint32_t prim, double t_min, double t_max) const {
-        uint32_t g = sc.gate_of[prim];
-        if (g == NO_GATE) return true;
-        const RayPre p = ray_pre(r);
-        bool ok = true;
-        do {
-            const DGate* __restrict__ gate = sc.gates + g;
-            double e;
-            ok = slab_test(&gate->box[0][0], r, p, t_min, t_max, &e);
-            g = gate->next;
-        } while (ok && g != NO_GATE);
-        return ok;
-    }
-    // After finished(): is `best` the reference's answer?
-    __device__ __forceinline__ bool confirm(const DScene& sc, double t_min, double t_max) const {
-        return careful || best.prim < 0 || gates_pass(sc, (uint32_t)best.prim, t_min, t_max);
+    // After finished(): is `best` the reference's answer?  Nearly always the cheap test on the
+    // shape's record says so; the reference's own arithmetic decides what is left.
+    __device__ __forceinline__ bool confirm(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) const {
+        if (careful || best.prim < 0) return true;
+        const ShapeRec* rec = SHAPES_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)best.prim * SHAPE_LDS_BYTES)
+                                            : sc.recs + best.prim;
+        if (cull.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) return true;
+        return gates_pass(sc.gates, sc.gate_of, (uint32_t)best.prim, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max);
     }
     __device__ __forceinline__ void begin_careful(const DScene& sc, double t_min, double t_max) {
         careful = true;
@@ -303,16 +339,15 @@ struct RayWalk {
         q0 = q1;
         --nq;
         const uint32_t index = entry & REF_INDEX_MASK;
-        const uint32_t tk = entry >> Q_KIND_SHIFT;
-        const double* p = SHAPES_IN_LDS ? reinterpret_cast<const double*>(lds.shapes + index * SHAPE_LDS_BYTES)
-                                        : sc.tparams + (size_t)index * TPARAMS_PER_SHAPE;
+        const uint32_t tk = (entry >> REF_KIND_SHIFT) & 7u;
+        const double* p = SHAPES_IN_LDS ? reinterpret_cast<const double*>(lds.shapes + index * SHAPE_LDS_BYTES) : sc.recs[index].f;
         double t;
         int side;
         if (tshape_hit(p, tk, r, dd, t_min, t_max, &t, &side)) {
             // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74)
             if (best.prim < 0 || t < best.t || (t == best.t && (int32_t)index > best.prim)) {
-                if (!careful || gates_pass(sc, index, t_min, t_max)) {
-                    best = HitRec{t, (int32_t)index, side};
+                if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max)) {
+                    best = HitRec{t, (int32_t)index, (int32_t)((uint32_t)side | ((entry >> REF_CLASS_SHIFT) & 63u) << CLASS_SHIFT)};
                     t_hi = fminf(t_hi, f32_not_below(t));
                 }
             }
@@ -323,7 +358,7 @@ struct RayWalk {
 // Per-wave persistent traversal of a queue of rays.
 //   Io::count()                      number of rays in the queue
 //   Io::load(i, &ray, &cookie)       ray i of the queue
-//   Io::store(i, cookie, hit)        its closest hit
+//   Io::store(i, cookie, t, prim, side, cls)   its closest hit (prim < 0: none) and the shade class of the shape
 //   work_counter                     device word, zero at launch: next unclaimed ray
 //   stack                            LDS, [level][BLOCK] entries of StackT
 //   tuning                           bits 0-7 `stay`: the wave stays in the node loop (or the
@@ -401,8 +436,9 @@ __device__ __forceinline__ void traverse_persistent(const DScene& sc, Io& io, ui
         const unsigned long long t0 = now();
         // finished rays leave at once
         if (active && walk.finished()) {
-            if (walk.confirm(sc, t_min, t_max)) {
-                io.store(i, cookie, walk.best);
+            if (walk.confirm(sc, lds, t_min, t_max)) {
+                io.store(i, cookie, walk.best.t, walk.best.prim, walk.best.side & (int32_t)walk.SIDE_MASK,
+                         ((uint32_t)walk.best.side >> walk.CLASS_SHIFT) & 7u);
                 active = false;
             } else {
                 walk.begin_careful(sc, t_min, t_max);  // rare: the winner's gate failed

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DScene sc, const mirt_ray* 
 constexpr int TRAV_BLOCK_LDS = 1024;
 constexpr int TRAV_BLOCK_GLOBAL = 512;
 
-// Dynamic LDS: [stack: levels x TBLOCK entries of StackT][nodes: n_nodes x 56 B][shapes: n_shapes x 80 B].
+// Dynamic LDS: [stack: levels x TBLOCK entries of StackT][nodes: n_nodes x 56 B][shapes: n_shapes x 136 B].
 __host__ __device__ inline size_t trav_stack_bytes(uint32_t levels, size_t entry, int tblock) {
     return (((size_t)levels * tblock * entry) + 15) & ~(size_t)15;
 }
@@ -175,8 +175,8 @@ __device__ __forceinline__ void stage_tree(const DScene& sc, char* lds_nodes, ch
         for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) dst[w] = src[w];
     }
     if (SHAPES) {
-        // the ten traversal parameters of every shape, as they lie in DScene::tparams
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.tparams);
+        // the shapes' records, as they lie in DScene::recs
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.recs);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_shapes);
         const uint32_t words = sc.n_shapes * (SHAPE_LDS_BYTES / 4);
         for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) dst[w] = src[w];
@@ -214,11 +214,11 @@ struct IntersectIo {
         r->time = rays[i].time;
         *cookie = i;
     }
-    __device__ __forceinline__ void store(uint32_t i, uint32_t, const HitRec& h) const {
+    __device__ __forceinline__ void store(uint32_t i, uint32_t, double t, int32_t prim, int32_t side, uint32_t) const {
         mirt_hit out;
-        out.prim = h.prim;
-        out.side = h.prim >= 0 ? h.side : 0;
-        out.t = h.prim >= 0 ? h.t : 0.0;
+        out.prim = prim;
+        out.side = prim >= 0 ? side : 0;
+        out.t = prim >= 0 ? t : 0.0;
         hits[i] = out;
     }
 };
@@ -303,13 +303,13 @@ struct ExtendIo {
         r->time = P.time[slot];
         *cookie = slot;
     }
-    __device__ __forceinline__ void store(uint32_t i, uint32_t slot, const HitRec& h) const {
+    __device__ __forceinline__ void store(uint32_t i, uint32_t slot, double t, int32_t prim, int32_t side, uint32_t shape_cls) const {
         uint32_t cls = SHADE_MISS;
         uint32_t ref = HIT_MISS;
-        if (h.prim >= 0) {
-            cls = shapes[h.prim].cls;
-            ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
-            P.hit_t[slot] = h.t;
+        if (prim >= 0) {
+            cls = shape_cls;
+            ref = (uint32_t)prim | ((uint32_t)side << HIT_SIDE_SHIFT);
+            P.hit_t[slot] = t;
         }
         P.hit_ref[slot] = ref;
         P.cls_q[i] = (uint8_t)cls;
@@ -382,6 +382,27 @@ __global__ __launch_bounds__(BLOCK) void k_bin(Paths P, RenderParams rp, uint32_
 }
 
 // ----------------------------------------------------------------------- shade
+// Development builds (MIRT_PATHS_STATS): wave clocks of the pieces of one shade trip.
+struct ShadeClock {
+#ifdef MIRT_PATHS_STATS
+    enum { N = 8 };
+    unsigned long long clk[N] = {}, last = 0;
+    __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int k) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        clk[k] += now - last;
+        last = now;
+    }
+#elif defined(MIRT_ISA_MARKS)
+    // analysis builds: the same places as comments in the assembly
+    __device__ __forceinline__ void start() { asm volatile("; SHADE_MARK start"); }
+    __device__ __forceinline__ void mark(int k) { asm volatile("; SHADE_MARK %0" ::"n"(k)); }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
+
 // What becomes of a path at a hit (or a miss): renderer.rs:99-116 for one bounce.
 struct ShadeResult {
     bool alive;     // the path goes on with the ray (origin, direction) and throughput `beta`
@@ -394,8 +415,9 @@ struct ShadeResult {
 // allowed; what would be scattered is multiplied by color(.., 0) = 0 (renderer.rs:99-101).
 template <int TEXTURES>
 __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls, const RayD& r, double hit_t, uint32_t hit_ref,
-                                                  const V3& beta, uint64_t stream, uint32_t bounce, bool last,
-                                                  const V3& background, const mirt_perlin* lds_tables, uint32_t n_staged) {
+                                                  uint32_t tk, const ShapeRec* rec, const mirt_texture* textures, const V3& beta, uint64_t stream, uint32_t bounce, bool last,
+                                                  const V3& background, const mirt_perlin* lds_tables, uint32_t n_staged,
+                                                  ShadeClock& clock) {
     ShadeResult out;
     out.alive = false;
     out.radiance = v3(0.0, 0.0, 0.0);
@@ -403,11 +425,15 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
         out.radiance = beta * background;  // renderer.rs:114
         return out;
     }
-    const Surface h = surface_at(sc, r, hit_t, hit_ref & HIT_PRIM_MASK, (int)(hit_ref >> HIT_SIDE_SHIFT));
-    const mirt_material* __restrict__ m = sc.materials + h.material;
+    const Surface h = surface_at(r, hit_t, tk, rec->f, (int)(hit_ref >> HIT_SIDE_SHIFT));
+    clock.mark(1);
+    // the material's constants from the shape's record; a texture that is not a constant is evaluated
+    const V3 color = v3(rec->color[0], rec->color[1], rec->color[2]);
+    const double param = rec->param;
+    const uint32_t texture = rec->texture;
     if (cls == SHADE_LIGHT) {
         // material.rs:144-152: no scatter, emit = texture value
-        out.radiance = beta * texture_value<TEXTURES>(sc, m->texture, h, lds_tables, n_staged);
+        out.radiance = beta * (texture == NO_TEXTURE ? color : texture_value<TEXTURES>(sc, textures, texture, h, lds_tables, n_staged));
         return out;
     }
     if (last) return out;
@@ -419,16 +445,19 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
     const bool is_lambertian = cls != SHADE_METAL && cls != SHADE_DIELECTRIC;
     V3 in_sphere = v3(0.0, 0.0, 0.0), unit_direction = v3(0.0, 0.0, 0.0);
     if (cls != SHADE_DIELECTRIC) in_sphere = random_in_unit_sphere(rng);
+    clock.mark(2);
     if (!is_lambertian) unit_direction = unit(r.d);
+    clock.mark(3);
     V3 dir, attenuation;
     bool scattered = true;
     if (cls == SHADE_METAL) {  // material.rs:74-91
         const V3 reflected = reflect(unit_direction, h.normal);
-        dir = reflected + m->param * in_sphere;
+        dir = reflected + param * in_sphere;
         scattered = dot(dir, h.normal) > 0.0;
-        attenuation = v3(m->albedo[0], m->albedo[1], m->albedo[2]);
+        attenuation = color;
+        clock.mark(4);
     } else if (cls == SHADE_DIELECTRIC) {  // material.rs:104-131
-        const double refraction_ratio = h.front_facing ? 1.0 / m->param : m->param;
+        const double refraction_ratio = h.front_facing ? 1.0 / param : param;
         const double cos_theta = fmin(dot(-unit_direction, h.normal), 1.0);
         const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
         const bool cannot_refract = refraction_ratio * sin_theta > 1.0;
@@ -438,10 +467,12 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
             dir = refract(unit_direction, h.normal, refraction_ratio);
         }
         attenuation = v3(1.0, 1.0, 1.0);
+        clock.mark(5);
     } else {  // the lambertian classes, material.rs:51-59
         const V3 target = h.p + h.normal + in_sphere;
         dir = target - h.p;
-        attenuation = texture_value<TEXTURES>(sc, m->texture, h, lds_tables, n_staged);
+        attenuation = cls == SHADE_LAMBERTIAN_CONSTANT ? color : texture_value<TEXTURES>(sc, textures, texture, h, lds_tables, n_staged);
+        clock.mark(6);
     }
     if (scattered) {
         out.alive = true;
@@ -455,6 +486,7 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
 // Perlin tables (9 KB each: 256 gradient vectors + 3 permutations) staged in LDS by the
 // kernels that shade.  The host pads DScene::perlins to PERLIN_STAGED readable tables.
 constexpr int PERLIN_STAGED = 2;
+constexpr int TEXTURES_STAGED = 32;  // entries of DScene::shade_textures the path kernel copies to LDS
 
 template <int NTHREADS>
 __device__ __forceinline__ void stage_perlin(const DScene& sc, mirt_perlin* dst_tables) {
@@ -514,7 +546,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
             const V3 beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
             RayD r{};
             double hit_t = 0.0;
-            uint32_t hit_ref = HIT_MISS;
+            uint32_t hit_ref = HIT_MISS, tk = 0;
+            const ShapeRec* rec = sc.recs;
             uint64_t stream = 0;
             if (cls != SHADE_MISS) {
                 r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
@@ -522,10 +555,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
                 r.time = P.time[slot];
                 hit_t = P.hit_t[slot];
                 hit_ref = P.hit_ref[slot];
+                tk = sc.shapes[hit_ref & HIT_PRIM_MASK].tk;
+                rec = sc.recs + (hit_ref & HIT_PRIM_MASK);
                 if (cls != SHADE_LIGHT && !last) stream = P.stream[slot];
             }
-            const ShadeResult s = shade_path<HAS_NOISE ? TEXTURES_ALL : TEXTURES_IMAGE>(sc, cls, r, hit_t, hit_ref, beta, stream, bounce, last, background, lds_tables,
-                                                                                                 n_staged);
+            ShadeClock clock;
+            const ShadeResult s = shade_path<HAS_NOISE ? TEXTURES_ALL : TEXTURES_IMAGE>(sc, cls, r, hit_t, hit_ref, tk, rec, sc.shade_textures, beta, stream, bounce, last, background, lds_tables,
+                                                                                                 n_staged, clock);
             alive = s.alive;
             if (alive) {
                 P.ox[slot] = s.origin.x; P.oy[slot] = s.origin.y; P.oz[slot] = s.origin.z;
@@ -585,6 +621,17 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
     const uint32_t n_staged = HAS_NOISE && sc.perlins ? (uint32_t)PERLIN_STAGED : 0u;
     if (n_staged) stage_perlin<PATHS_BLOCK>(sc, s_perlin);
     const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
+    // the textures shading can meet (one checker and its two colours, say), in LDS when they are few
+    __shared__ mirt_texture s_textures[TEXTURES > TEXTURES_CONSTANT ? TEXTURES_STAGED : 1];
+    const mirt_texture* textures = sc.shade_textures;
+    if (TEXTURES > TEXTURES_CONSTANT && sc.n_shade_textures <= (uint32_t)TEXTURES_STAGED) {
+        const uint32_t words = sc.n_shade_textures * (uint32_t)(sizeof(mirt_texture) / 4);
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.shade_textures);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_textures);
+        for (uint32_t w = threadIdx.x; w < words; w += PATHS_BLOCK) dst[w] = src[w];
+        textures = s_textures;
+        __syncthreads();
+    }
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
     char* lds_shapes = lds_nodes + trav_nodes_bytes(sc.n_nodes);
@@ -602,6 +649,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
     // (have, walk finished).  Per trip the wave refills empty lanes, then runs the piece of
     // code -- node visits, shape tests, shading -- that enough lanes are waiting for.
     bool have = false, exhausted = false;
+    uint32_t next = 0, chunk_end = 0;  // the wave's chunk of the queue (wave-uniform)
+    const uint32_t chunk = chunk_rays(n, gridDim.x * (PATHS_BLOCK / 64));
     uint32_t slot = 0, bounce = 0, extra_segments = 0;
     V3 beta = v3(0.0, 0.0, 0.0);
     uint64_t stream = 0;
@@ -613,6 +662,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
     // development build: wave clocks and lane counts per piece of code, summed into P.segments[2..]
     enum { PS_REFILL, PS_SHADE, PS_NODE, PS_LEAF, PS_N };
     unsigned long long ps_clk[PS_N] = {}, ps_trips[PS_N] = {}, ps_lanes[PS_N] = {};
+    ShadeClock shade_clock;
     const unsigned long long ps_begin = __builtin_amdgcn_s_memtime();
 #define PS_START() const unsigned long long ps_t0 = __builtin_amdgcn_s_memtime()
 #define PS_STOP(k, lanes)                                                   \
@@ -622,19 +672,28 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
         ps_lanes[k] += (lanes);                                             \
     } while (0)
 #else
+    ShadeClock shade_clock;
 #define PS_START() do {} while (0)
 #define PS_STOP(k, lanes) do {} while (0)
 #endif
     for (;;) {
         const unsigned long long need = __ballot(!have);
-        // one queue access (a global atomic) serves many lanes: wait until enough are empty
+        // one refill serves many lanes: wait until enough are empty.  Path indices come from the
+        // wave's own chunk of the queue; one global atomic fetches the next chunk.
         if (!exhausted && (__popcll(need) >= refill_at || need == ~0ull)) {
             PS_START();
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(work, (uint32_t)__popcll(need));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t i = base + mbcnt_lt(need);
-            if (!have && i < n) {
+            if (next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                next = base;
+                chunk_end = min(base + chunk, n);
+                exhausted = base >= n;
+            }
+            const uint32_t avail = exhausted ? 0u : chunk_end - next;
+            const uint32_t rank = mbcnt_lt(need);
+            const uint32_t i = next + rank;
+            if (!have && rank < avail) {
                 RayD r;
                 if (bounce0 == 0) {
                     // slot i = sample (sample_base + i / n_pixels) of the (i % n_pixels)-th pixel, as in k_raygen
@@ -656,7 +715,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
                 have = true;
                 walk.begin(sc, r, rp.t_min, rp.t_max);
             }
-            exhausted = base + (uint32_t)__popcll(need) >= n;
+            next += min((uint32_t)__popcll(need), avail);
             PS_STOP(PS_REFILL, __popcll(need));
         }
         const int n_node = __popcll(__ballot(have && walk.wants_node()));
@@ -668,17 +727,23 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
         }
         if (n_shade >= shade_at || n_node + n_leaf == 0) {
             PS_START();
-            if (have && walk.finished() && !walk.confirm(sc, rp.t_min, rp.t_max)) walk.begin_careful(sc, rp.t_min, rp.t_max);
+            shade_clock.start();
+            if (have && walk.finished() && !walk.confirm(sc, lds, rp.t_min, rp.t_max)) walk.begin_careful(sc, rp.t_min, rp.t_max);
+            shade_clock.mark(0);
             if (have && walk.finished()) {
                 if (bounce != bounce0) ++extra_segments;
                 const HitRec h = walk.best;
-                uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS;
+                uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS, tk = 0;
+                const ShapeRec* rec = sc.recs;
                 if (h.prim >= 0) {
-                    cls = sc.shapes[h.prim].cls;
-                    hit_ref = (uint32_t)h.prim | ((uint32_t)h.side << HIT_SIDE_SHIFT);
+                    cls = ((uint32_t)h.side >> walk.CLASS_SHIFT) & 7u;
+                    tk = ((uint32_t)h.side >> walk.TK_SHIFT) & 7u;
+                    hit_ref = (uint32_t)h.prim | (((uint32_t)h.side & walk.SIDE_MASK) << HIT_SIDE_SHIFT);
+                    rec = TREE_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)h.prim * SHAPE_LDS_BYTES) : sc.recs + h.prim;
                 }
                 const bool last = bounce + 1 == rp.max_depth;
-                const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, beta, stream, bounce, last, background, lds_tables, n_staged);
+                const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, stream, bounce, last, background, lds_tables, n_staged,
+                                                           shade_clock);
                 if (s.alive) {
                     RayD r;
                     r.o = s.origin;
@@ -693,6 +758,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
                     walk.reset();
                 }
             }
+            shade_clock.mark(7);
             PS_STOP(PS_SHADE, n_shade);
             continue;
         }
@@ -731,6 +797,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
             atomicAdd(P.segments + 4 + 3 * k, ps_lanes[k]);
         }
         atomicAdd(P.segments + 2 + 3 * PS_N, (unsigned long long)(__builtin_amdgcn_s_memtime() - ps_begin));
+        for (int k = 0; k < ShadeClock::N; ++k) atomicAdd(P.segments + 3 + 3 * PS_N + k, shade_clock.clk[k]);
     }
 #endif
 #undef PS_START

@@ -266,11 +266,18 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     }
 
     std::vector<uint32_t> tkinds;
-    std::vector<double> tparams;
-    traversal_shapes(desc, &tkinds, &tparams);
+    std::vector<ShapeRec> recs;
+    std::vector<mirt_texture> shade_textures;
+    traversal_shapes(desc, &tkinds, &recs);
+    shading_records(desc, &recs, &shade_textures);
+    std::vector<uint32_t> ref_bits(desc->n_shapes);  // what a leaf reference says about its shape
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        shapes[i].tk = tkinds[i];
+        ref_bits[i] = (tkinds[i] << REF_KIND_SHIFT) | (shapes[i].cls << REF_CLASS_SHIFT);
+    }
     BuiltTree tree;
     if (desc->nodes) {
-        tree = build_fast_tree(desc, tkinds.data(), MAX_TREE_HEIGHT);
+        tree = build_fast_tree(desc, ref_bits.data(), MAX_TREE_HEIGHT);
         if (tree.height > (uint32_t)MAX_TREE_HEIGHT)
             return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", tree.height, MAX_TREE_HEIGHT);
         // the reference-order kernel walks the caller's own members: bound their depth too
@@ -284,6 +291,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
         if (deepest > (uint32_t)MAX_TREE_HEIGHT)
             return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", deepest, MAX_TREE_HEIGHT);
     }
+    if (desc->nodes) sure_boxes(tree, &recs);
     const std::vector<CNode>& nodes = tree.nodes;
     const uint32_t root_ref = tree.root_ref, height = tree.height;
 
@@ -319,7 +327,8 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
         }                                                                                                 \
     } while (0)
     DShape* d_shapes = nullptr;
-    double* d_tparams = nullptr;
+    ShapeRec* d_recs = nullptr;
+    mirt_texture* d_shade_textures = nullptr;
     CNode* d_nodes = nullptr;
     DGate* d_gates = nullptr;
     uint32_t* d_gate_of = nullptr;
@@ -329,7 +338,8 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     mirt_perlin* d_perlins = nullptr;
     mirt_image* d_images = nullptr;
     SCENE_TRY(upload(&d_shapes, shapes.data(), shapes.size()));
-    SCENE_TRY(upload(&d_tparams, tparams.data(), tparams.size()));
+    SCENE_TRY(upload(&d_recs, recs.data(), recs.size()));
+    SCENE_TRY(upload(&d_shade_textures, shade_textures.data(), shade_textures.size()));
     SCENE_TRY(upload(&d_nodes, nodes.data(), nodes.size()));
     SCENE_TRY(upload(&d_gates, tree.gates.data(), tree.gates.size()));
     SCENE_TRY(upload(&d_gate_of, tree.gate_of.data(), tree.gate_of.size()));
@@ -348,7 +358,9 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     SCENE_TRY(upload(&d_images, images.data(), images.size()));
 #undef SCENE_TRY
     sc->d.shapes = d_shapes;
-    sc->d.tparams = d_tparams;
+    sc->d.recs = d_recs;
+    sc->d.shade_textures = d_shade_textures;
+    sc->d.n_shade_textures = (uint32_t)shade_textures.size();
     sc->d.nodes = d_nodes;
     sc->d.gates = d_gates;
     sc->d.gate_of = d_gate_of;
@@ -682,7 +694,8 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     p.levels = std::max<uint32_t>(scene->height, 1);
     p.stack16 = scene->d.n_nodes < 65536u;
     const size_t tree = trav_nodes_bytes(scene->d.n_nodes) + (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
-    const size_t fixed = textures >= TEXTURES_ALL ? sizeof(mirt_perlin) * PERLIN_STAGED : 0;
+    const size_t fixed = (textures >= TEXTURES_ALL ? sizeof(mirt_perlin) * PERLIN_STAGED : 0) +
+                         (textures > TEXTURES_CONSTANT ? sizeof(mirt_texture) * TEXTURES_STAGED : 0);
     // tree in LDS: ONE workgroup per CU, as many waves as the registers allow, sharing one copy
     const int big = paths_block(textures, true);
     const size_t big_stack = trav_stack_bytes(p.levels, 2, big);
@@ -787,7 +800,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     // ---- per-pass state: radiance records, counters and totals in one block (kept by the
     // scene between calls), the queue pipeline's path state in arrays of this call
     const Counters C{max_depth};
-    constexpr size_t N_SEGMENT_WORDS = 2 + 16;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
+    constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
     auto round256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t radiance_bytes = round256((size_t)capacity * sizeof(double4));
     const size_t counters_bytes = round256((size_t)C.total() * sizeof(uint32_t));
@@ -930,6 +943,9 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
                          names[k], 100.0 * clk / total, trips, trips ? clk / trips : 0.0, trips ? lanes / trips : 0.0);
         }
         std::fprintf(stderr, "[k_paths] other  %5.1f %%\n", 100.0 * (total - sum) / total);
+        const char* parts[8] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "next ray / store"};
+        for (int k = 0; k < 8; ++k)
+            std::fprintf(stderr, "[k_paths]   shade: %-20s %5.1f %% of wave clocks\n", parts[k], 100.0 * (double)segments[2 + 13 + k] / total);
     }
 #endif
 

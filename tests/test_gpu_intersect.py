@@ -93,3 +93,88 @@ def test_camera_rays_match_oracle(oracle):
         ref[idx] = (tuple(r.origin), tuple(r.direction), r.time)
     for f in ("origin", "direction", "time"):
         assert np.array_equal(gpu[f], ref[f]), f
+
+
+def _mixed_scene(n=96, seed=3):
+    """Spheres (some with negative radius, some moving), rects and cubes scattered in a 40-unit cell."""
+    import scene_util as su
+
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for k in range(n):
+        c = rng.uniform(-20.0, 20.0, 3)
+        kind = k % 8
+        if kind == 0:
+            shapes.append(su.moving_sphere(c, c + rng.uniform(-1.0, 1.0, 3), rng.uniform(0.3, 1.5), 0.0, 1.0))
+        elif kind == 1:
+            shapes.append(su.sphere(*c, -rng.uniform(0.3, 1.5)))
+        elif kind == 2:
+            a = rng.uniform(0.5, 3.0, 2)
+            shapes.append(su.shape(abi.SHAPE_XY_RECT + int(rng.integers(0, 3)), 0, c[0], c[0] + a[0], c[1], c[1] + a[1], c[2]))
+        elif kind == 3:
+            shapes.append(su.shape(abi.SHAPE_CUBE, 0, *c, *(c + rng.uniform(0.5, 3.0, 3))))
+        else:
+            shapes.append(su.sphere(*c, rng.uniform(0.3, 1.5)))
+    return su.Built(shapes, seed=seed)
+
+
+def _random_rays(n, seed, times=(0.0, 1.0)):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=api.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-30.0, 30.0, (n, 3))
+    target = rng.uniform(-20.0, 20.0, (n, 3))
+    rays["direction"] = (target - rays["origin"]) * rng.uniform(0.2, 3.0, (n, 1))
+    rays["time"] = rng.uniform(times[0], times[1], n)
+    # some rays along an axis: zero direction components, the inf / NaN paths of the slab test
+    k = n // 16
+    rays["direction"][:k, 1] = 0.0
+    rays["direction"][k // 2:k, 2] = 0.0
+    rays["direction"][:k // 4, 0] = -0.0
+    return rays
+
+
+@pytest.mark.parametrize("boxes", ["as built", "shrunk", "scrambled"])
+def test_reference_boxes_decide_which_shapes_are_reached(boxes, oracle):
+    """The reference reaches a shape only through the boxes above it (bvh.rs:61-66), whatever they
+    are.  'shrunk' scales every box toward a point (boxes still nest but cut into their shapes),
+    'scrambled' moves every bound at random (boxes no longer nest): in both, many rays hit a shape
+    geometrically that the reference never tests, and the answer must still be the reference's."""
+    built = _mixed_scene()
+    rng = np.random.default_rng(11)
+    for i in range(built.desc.n_nodes):
+        m = built.nodes[i]
+        if m.is_leaf:
+            continue
+        for a in range(3):
+            if boxes == "shrunk":
+                m.bmin[a] = 1.0 + (m.bmin[a] - 1.0) * 0.8
+                m.bmax[a] = 1.0 + (m.bmax[a] - 1.0) * 0.8
+            elif boxes == "scrambled":
+                m.bmin[a] += rng.uniform(-1.0, 2.0)
+                m.bmax[a] += rng.uniform(-2.0, 1.0)
+    rays = _random_rays(200_000, 5)
+    ref, _ = oracle.intersect(built.desc, rays)
+    everything, _ = oracle.intersect(built.desc, rays, use_bvh=False)
+    if boxes != "as built":
+        # the altered boxes do change answers: the test would be vacuous otherwise
+        assert np.count_nonzero(ref["prim"] != everything["prim"]) > 1000
+    scene = api.Scene(built.desc)
+    try:
+        for trav, label in ((abi.TRAVERSE_REFERENCE, "reference-order"), (abi.TRAVERSE_FAST, "fast")):
+            _compare(scene.hit(rays, traversal=trav), ref, f"{boxes} boxes, {label}")
+    finally:
+        scene.close()
+
+
+def test_ray_times_outside_the_shutter_and_finite_range(oracle):
+    """Moving spheres are boxed over their own time span; a ray at any other time, and a query
+    with a finite (t_min, t_max), still get the reference's answer."""
+    built = _mixed_scene(seed=4)
+    rays = _random_rays(100_000, 6, times=(-3.0, 4.0))
+    scene = api.Scene(built.desc)
+    try:
+        for t_min, t_max in ((0.001, float("inf")), (0.25, 1.0), (-5.0, 0.5)):
+            ref, _ = oracle.intersect(built.desc, rays, t_min=t_min, t_max=t_max)
+            _compare(scene.hit(rays, t_min=t_min, t_max=t_max), ref, f"range ({t_min}, {t_max})")
+    finally:
+        scene.close()
