@@ -14,8 +14,9 @@ samples and the f64 accumulation images are summed with one RCCL reduce.
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with
 the algorithmic bytes of DESIGN.md: the path kernel (whole paths in registers, 24 bytes of
 radiance out per sample) in the default mode, the closest-hit kernel of the per-bounce
-pipeline with --handover -1.  Neither is bound by HBM: `roofline.valu_f64` prices the same
-kernel against the f64 vector ALU, which is what limits it.
+pipeline with --handover -1.  Neither is bound by HBM: the path kernel saturates the vector
+ALU's issue slots (`roofline.valu_issue_busy`, measured), and `roofline.valu_f64` prices the
+reference traversal of the same rays against the f64 vector ALU.
 `cpu_baseline` times the CPU oracle (a C++ restatement of the reference algorithm,
 not the reference itself: no Rust toolchain exists here) on a bounded sample of the
 same workload on the host cores of the same box.
@@ -193,7 +194,7 @@ def main():
                 "width": W, "height": H, "spp": spp, "max_depth": api.MAX_DEPTH,
                 "shapes": world.n_shapes, "bvh_members": world.n_nodes,
                 "split": args.split if world_size > 1 else "none",
-                "traversal": "fast (near-first, distance-pruned, reference hit/miss decisions)",
+                "traversal": "fast (f32 culling tree, near-first, distance-pruned; reference boxes decide which hits count)",
             },
             "handover": {"bounce": int(step_stats[-1]["handover_bounce"]),
                          "path_kernel_segments_frac": tot["segments_paths"] / max(1.0, tot["segments"])},
@@ -221,8 +222,8 @@ def main():
                 "launches": launches,
                 "note": "algorithmic bytes = what a queue-per-bounce pipeline moves through HBM for these segments (ray 56 + hit "
                         "16 + path state 88 in, 88 out + two queue indices 8 = 272 B per segment, 24 B per sample); this kernel keeps "
-                        "all of it in registers, so `traffic` (measured) is far below it and the kernel is bound by the f64 vector "
-                        "ALU (valu_f64), not by HBM",
+                        "all of it in registers, so `traffic` (measured) is far below it and the kernel is bound by vector-"
+                        "instruction issue (valu_issue_busy, from the PMC passes under profiles/), not by HBM",
             }
             # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 runs of this
             # same workload, committed under profiles/), scaled to this run's paths per launch
@@ -231,6 +232,8 @@ def main():
                 with open(pmc_path) as f:
                     pmc = json.load(f)
                 result["roofline"]["traffic"] = pmc["hbm_bytes_per_path"] * samples / launches
+                result["roofline"]["valu_issue_busy"] = pmc.get("valu_issue_busy_share_of_simd_cycles")
+                result["roofline"]["lanes_active_per_valu_instruction"] = pmc.get("lanes_active_per_valu_instruction")
                 result["roofline"]["traffic_source"] = "profiles/r01_pmc_k_paths.json (bytes per path x paths per launch)"
         elif profile and tot["ms_extend"] > 0:
             launches = tot["launches_extend"]

@@ -183,9 +183,12 @@ enum {
      * visited, both children with the same t_max, combined exactly as
      * bvh.rs:68-79 does (left wins only if left.t < right.t). */
     MIRT_TRAVERSE_REFERENCE = 0,
-    /* Same hit/miss decisions at every box, near child first, and a subtree
-     * is additionally skipped when its slab entry distance exceeds the best t
-     * found so far by a safety margin; ties resolved as bvh.rs:70-74 would. */
+    /* The same answer by another route: the closest hit among all shapes is found
+     * through a culling tree of the library's own (near child first, subtrees
+     * beyond the best t skipped with a safety margin); it counts only if
+     * AABB::hit passes for the boxes above its shape, tested in the reference's
+     * arithmetic, else the query is repeated with that test on every hit; ties
+     * resolved as bvh.rs:70-74 would. */
     MIRT_TRAVERSE_FAST = 1
 };
 

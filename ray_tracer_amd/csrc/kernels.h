@@ -405,10 +405,9 @@ struct ShadeClock {
 
 // What becomes of a path at a hit (or a miss): renderer.rs:99-116 for one bounce.
 struct ShadeResult {
-    bool alive;     // the path goes on with the ray (origin, direction) and throughput `beta`
+    bool alive;     // the path goes on with the ray (origin, direction)
     V3 origin, direction;
-    V3 beta;
-    V3 radiance;    // value of the finished path when !alive
+    V3 value;       // alive: the path's new throughput; otherwise: the radiance of the finished path
 };
 
 // cls: shade class of the hit shape (SHADE_MISS: none).  `last`: this is the deepest bounce
@@ -420,9 +419,9 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
                                                   ShadeClock& clock) {
     ShadeResult out;
     out.alive = false;
-    out.radiance = v3(0.0, 0.0, 0.0);
+    out.value = v3(0.0, 0.0, 0.0);
     if (cls == SHADE_MISS) {
-        out.radiance = beta * background;  // renderer.rs:114
+        out.value = beta * background;  // renderer.rs:114
         return out;
     }
     const Surface h = surface_at(r, hit_t, tk, rec->f, (int)(hit_ref >> HIT_SIDE_SHIFT));
@@ -433,7 +432,7 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
     const uint32_t texture = rec->texture;
     if (cls == SHADE_LIGHT) {
         // material.rs:144-152: no scatter, emit = texture value
-        out.radiance = beta * (texture == NO_TEXTURE ? color : texture_value<TEXTURES>(sc, textures, texture, h, lds_tables, n_staged));
+        out.value = beta * (texture == NO_TEXTURE ? color : texture_value<TEXTURES>(sc, textures, texture, h, lds_tables, n_staged));
         return out;
     }
     if (last) return out;
@@ -478,7 +477,7 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
         out.alive = true;
         out.origin = h.p;
         out.direction = dir;
-        out.beta = beta * attenuation;  // (emitted + attenuation) with emitted = 0, renderer.rs:107
+        out.value = beta * attenuation;  // (emitted + attenuation) with emitted = 0, renderer.rs:107
     }
     return out;
 }
@@ -566,9 +565,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
             if (alive) {
                 P.ox[slot] = s.origin.x; P.oy[slot] = s.origin.y; P.oz[slot] = s.origin.z;
                 P.dx[slot] = s.direction.x; P.dy[slot] = s.direction.y; P.dz[slot] = s.direction.z;
-                P.bx[slot] = s.beta.x; P.by[slot] = s.beta.y; P.bz[slot] = s.beta.z;
+                P.bx[slot] = s.value.x; P.by[slot] = s.value.y; P.bz[slot] = s.value.z;
             } else {
-                store_radiance(P, slot, s.radiance);
+                store_radiance(P, slot, s.value);
             }
         }
         // ---- append survivors: ballot per wave, one atomic per block step
@@ -608,7 +607,24 @@ __host__ __device__ constexpr int paths_waves(int textures) { return textures <=
 __host__ __device__ constexpr int paths_block(int textures, bool tree_in_lds) { return tree_in_lds ? 256 * paths_waves(textures) : 256; }
 // bits 0-7: as in traverse_persistent; bits 8-15: lanes waiting to be shaded that trigger
 // shading; bits 16-23: empty lanes that trigger a refill from the queue
-constexpr uint32_t PATHS_TUNING_DEFAULT = 2u | (48u << 8) | (16u << 16);
+constexpr uint32_t PATHS_TUNING_DEFAULT = 3u | (48u << 8) | (16u << 16);
+
+// A kernel argument read from the argument block (constant address space: scalar loads) at byte `offset`.
+typedef const __attribute__((address_space(4))) uint32_t* KernargWords;
+template <class T>
+__device__ __forceinline__ T load_kernarg(KernargWords args, size_t offset) {
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) <= 8, "whole 8-byte words");
+    T value;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&value);
+    const __attribute__((address_space(4))) unsigned long long* src =
+        (const __attribute__((address_space(4))) unsigned long long*)(args + offset / 4);
+#pragma unroll
+    for (size_t w = 0; w < sizeof(T) / 8; ++w) dst[w] = src[w];
+    return value;
+}
+
+static_assert(sizeof(DScene) % 8 == 0 && sizeof(Paths) % 8 == 0 && alignof(DScene) == 8 && alignof(Paths) == 8 && alignof(RenderParams) == 8,
+              "k_paths finds its second and third argument at sizeof(DScene) and sizeof(DScene) + sizeof(Paths) of the argument block");
 
 template <class StackT, int TEXTURES, bool TREE_IN_LDS>
 __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(
@@ -640,7 +656,6 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
 
     const Counters C{rp.max_depth};
     const uint32_t n = bounce0 == 0 ? rp.n_paths : P.counters[C.live(bounce0)];
-    const uint32_t* __restrict__ qin = P.live[bounce0 & 1];
     uint32_t* __restrict__ work = P.counters + C.work(bounce0);
     const V3 background = v3(rp.background[0], rp.background[1], rp.background[2]);
     const uint32_t tid = threadIdx.x, lane = lane_id();
@@ -694,22 +709,30 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
             const uint32_t rank = mbcnt_lt(need);
             const uint32_t i = next + rank;
             if (!have && rank < avail) {
+                // What only a refill reads -- the camera, the pixel set, the queue pipeline's arrays: some
+                // hundred scalar registers' worth -- is read from the kernel's argument block HERE, through
+                // a pointer the compiler cannot see through, instead of being held (and spilled) around
+                // the whole loop.
+                KernargWords args = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(args));
                 RayD r;
                 if (bounce0 == 0) {
+                    const RenderParams q = load_kernarg<RenderParams>(args, sizeof(DScene) + sizeof(Paths));
                     // slot i = sample (sample_base + i / n_pixels) of the (i % n_pixels)-th pixel, as in k_raygen
                     slot = i;
-                    const uint32_t idx = rp.px.idx(slot % rp.n_pixels);
-                    PathRng rng{mirt_rng_stream(rp.seed, idx, rp.sample_base + slot / rp.n_pixels), 0u, 0u};
-                    r = camera_ray(rp.cam, rp.width, rp.height, idx, rng);
+                    const uint32_t idx = q.px.idx(slot % q.n_pixels);
+                    PathRng rng{mirt_rng_stream(q.seed, idx, q.sample_base + slot / q.n_pixels), 0u, 0u};
+                    r = camera_ray(q.cam, q.width, q.height, idx, rng);
                     beta = v3(1.0, 1.0, 1.0);
                     stream = rng.stream;
                 } else {
-                    slot = qin[i];
-                    r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
-                    r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
-                    r.time = P.time[slot];
-                    beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
-                    stream = P.stream[slot];
+                    const Paths Q = load_kernarg<Paths>(args, sizeof(DScene));
+                    slot = ((bounce0 & 1) ? Q.live[1] : Q.live[0])[i];
+                    r.o = v3(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
+                    r.d = v3(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
+                    r.time = Q.time[slot];
+                    beta = v3(Q.bx[slot], Q.by[slot], Q.bz[slot]);
+                    stream = Q.stream[slot];
                 }
                 bounce = bounce0;
                 have = true;
@@ -744,16 +767,19 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
                 const bool last = bounce + 1 == rp.max_depth;
                 const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, stream, bounce, last, background, lds_tables, n_staged,
                                                            shade_clock);
+                // (the store comes last: whatever the next instructions wait for in memory, they would
+                // wait for it too)
                 if (s.alive) {
                     RayD r;
                     r.o = s.origin;
                     r.d = s.direction;
                     r.time = walk.r.time;
-                    beta = s.beta;
+                    beta = s.value;
                     ++bounce;
                     walk.begin(sc, r, rp.t_min, rp.t_max);
-                } else {
-                    store_radiance(P, slot, s.radiance);
+                }
+                if (!s.alive) {
+                    store_radiance(P, slot, s.value);
                     have = false;
                     walk.reset();
                 }

@@ -95,42 +95,7 @@ def test_camera_rays_match_oracle(oracle):
         assert np.array_equal(gpu[f], ref[f]), f
 
 
-def _mixed_scene(n=96, seed=3):
-    """Spheres (some with negative radius, some moving), rects and cubes scattered in a 40-unit cell."""
-    import scene_util as su
-
-    rng = np.random.default_rng(seed)
-    shapes = []
-    for k in range(n):
-        c = rng.uniform(-20.0, 20.0, 3)
-        kind = k % 8
-        if kind == 0:
-            shapes.append(su.moving_sphere(c, c + rng.uniform(-1.0, 1.0, 3), rng.uniform(0.3, 1.5), 0.0, 1.0))
-        elif kind == 1:
-            shapes.append(su.sphere(*c, -rng.uniform(0.3, 1.5)))
-        elif kind == 2:
-            a = rng.uniform(0.5, 3.0, 2)
-            shapes.append(su.shape(abi.SHAPE_XY_RECT + int(rng.integers(0, 3)), 0, c[0], c[0] + a[0], c[1], c[1] + a[1], c[2]))
-        elif kind == 3:
-            shapes.append(su.shape(abi.SHAPE_CUBE, 0, *c, *(c + rng.uniform(0.5, 3.0, 3))))
-        else:
-            shapes.append(su.sphere(*c, rng.uniform(0.3, 1.5)))
-    return su.Built(shapes, seed=seed)
-
-
-def _random_rays(n, seed, times=(0.0, 1.0)):
-    rng = np.random.default_rng(seed)
-    rays = np.zeros(n, dtype=api.RAY_DTYPE)
-    rays["origin"] = rng.uniform(-30.0, 30.0, (n, 3))
-    target = rng.uniform(-20.0, 20.0, (n, 3))
-    rays["direction"] = (target - rays["origin"]) * rng.uniform(0.2, 3.0, (n, 1))
-    rays["time"] = rng.uniform(times[0], times[1], n)
-    # some rays along an axis: zero direction components, the inf / NaN paths of the slab test
-    k = n // 16
-    rays["direction"][:k, 1] = 0.0
-    rays["direction"][k // 2:k, 2] = 0.0
-    rays["direction"][:k // 4, 0] = -0.0
-    return rays
+from golden_cases import _mixed_scene, _random_rays  # noqa: E402
 
 
 @pytest.mark.parametrize("boxes", ["as built", "shrunk", "scrambled"])

@@ -23,7 +23,9 @@ def main(path, paths_per_launch, command):
         "hbm_bytes_note": "FETCH_SIZE doubled (gfx950 counts 128-byte read requests as 64 bytes); WRITE_SIZE as reported",
         "hbm_bytes_per_path": hbm / paths_per_launch,
         "lanes_active_per_valu_instruction": per_launch["SQ_THREAD_CYCLES_VALU"] / per_launch["SQ_INSTS_VALU"],
-        "valu_busy_share_of_wave_cycles": 4.0 * per_launch["SQ_ACTIVE_INST_VALU"] / per_launch["SQ_WAVE_CYCLES"],
+        # every wave lives as long as the kernel, SQ_WAVES / 1024 of them share one of the 1024 SIMDs: the
+        # SIMD's cycles are the wave cycles divided by that, and a SIMD issues one vector instruction at a time
+        "valu_issue_busy_share_of_simd_cycles": per_launch["SQ_ACTIVE_INST_VALU"] / (per_launch["SQ_WAVE_CYCLES"] / (per_launch["SQ_WAVES"] / 1024.0)),
         "valu_instructions_per_path": per_launch["SQ_INSTS_VALU"] * 64.0 / paths_per_launch,
     }
     print(json.dumps(out, indent=1))
