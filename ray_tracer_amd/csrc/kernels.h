@@ -403,6 +403,12 @@ struct ShadeClock {
 #endif
 };
 
+// Will shade_path use a sample of random_in_unit_sphere for a hit of class `cls`?
+// (lambertian, material.rs:53; metal, material.rs:79)
+__device__ __forceinline__ bool wants_in_sphere(uint32_t cls, bool last) {
+    return !last && cls != SHADE_MISS && cls != SHADE_LIGHT && cls != SHADE_DIELECTRIC;
+}
+
 // What becomes of a path at a hit (or a miss): renderer.rs:99-116 for one bounce.
 struct ShadeResult {
     bool alive;     // the path goes on with the ray (origin, direction)
@@ -414,8 +420,8 @@ struct ShadeResult {
 // allowed; what would be scattered is multiplied by color(.., 0) = 0 (renderer.rs:99-101).
 template <int TEXTURES>
 __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls, const RayD& r, double hit_t, uint32_t hit_ref,
-                                                  uint32_t tk, const ShapeRec* rec, const mirt_texture* textures, const V3& beta, uint64_t stream, uint32_t bounce, bool last,
-                                                  const V3& background, const mirt_perlin* lds_tables, uint32_t n_staged,
+                                                  uint32_t tk, const ShapeRec* rec, const mirt_texture* textures, const V3& beta,
+                                                  const V3& in_sphere, uint64_t stream, uint32_t bounce, bool last, const V3& background, const mirt_perlin* lds_tables, uint32_t n_staged,
                                                   ShadeClock& clock) {
     ShadeResult out;
     out.alive = false;
@@ -437,13 +443,13 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
     }
     if (last) return out;
     // Lanes of one wave may hold hits of different classes (path kernel): what several classes
-    // need is computed ONCE for all of them before the class branches -- the rejection loop of
-    // random_in_unit_sphere (first draws of the stage for lambertian and metal alike) and the
-    // unit direction (metal, dielectric) -- instead of once per class present in the wave.
-    PathRng rng{stream, bounce + 1u, 0u};
+    // need is computed ONCE for all of them before the class branches -- `in_sphere`, the result
+    // of random_in_unit_sphere (first draws of the stage for lambertian and metal alike; the
+    // caller had the whole wave work on it, see wants_in_sphere) and the unit direction (metal,
+    // dielectric) -- instead of once per class present in the wave.
+    PathRng rng{stream, bounce + 1u, 0u};  // dielectric: its one draw is the first of the stage
     const bool is_lambertian = cls != SHADE_METAL && cls != SHADE_DIELECTRIC;
-    V3 in_sphere = v3(0.0, 0.0, 0.0), unit_direction = v3(0.0, 0.0, 0.0);
-    if (cls != SHADE_DIELECTRIC) in_sphere = random_in_unit_sphere(rng);
+    V3 unit_direction = v3(0.0, 0.0, 0.0);
     clock.mark(2);
     if (!is_lambertian) unit_direction = unit(r.d);
     clock.mark(3);
@@ -503,6 +509,7 @@ template <bool HAS_NOISE>
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParams rp, uint32_t bounce) {
     __shared__ uint32_t s_cnt[2][WAVES_PER_BLOCK];
     __shared__ uint32_t s_base[2];
+    __shared__ unsigned long long s_scratch[WAVES_PER_BLOCK][IN_SPHERE_SCRATCH];
     __shared__ mirt_perlin s_perlin[HAS_NOISE ? PERLIN_STAGED : 1];
     const uint32_t n_staged = HAS_NOISE && sc.perlins ? (uint32_t)PERLIN_STAGED : 0u;
     if (n_staged) stage_perlin<BLOCK>(sc, s_perlin);
@@ -540,14 +547,17 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
         cls = __builtin_amdgcn_readfirstlane(cls);  // wave-uniform by construction
         bool alive = false;
         uint32_t slot = 0;
+        if (valid) slot = P.cls_queue[(size_t)cls * P.capacity + first + lane];
+        uint64_t stream = 0;
+        const bool sampling = valid && wants_in_sphere(cls, last);
+        if (valid && cls != SHADE_MISS && cls != SHADE_LIGHT && !last) stream = P.stream[slot];
+        const V3 in_sphere = random_in_unit_sphere_wave(sampling, PathRng{stream, bounce + 1u, 0u}, s_scratch[wave]);
         if (valid) {
-            slot = P.cls_queue[(size_t)cls * P.capacity + first + lane];
             const V3 beta = v3(P.bx[slot], P.by[slot], P.bz[slot]);
             RayD r{};
             double hit_t = 0.0;
             uint32_t hit_ref = HIT_MISS, tk = 0;
             const ShapeRec* rec = sc.recs;
-            uint64_t stream = 0;
             if (cls != SHADE_MISS) {
                 r.o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
                 r.d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
@@ -556,10 +566,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
                 hit_ref = P.hit_ref[slot];
                 tk = sc.shapes[hit_ref & HIT_PRIM_MASK].tk;
                 rec = sc.recs + (hit_ref & HIT_PRIM_MASK);
-                if (cls != SHADE_LIGHT && !last) stream = P.stream[slot];
             }
             ShadeClock clock;
-            const ShadeResult s = shade_path<HAS_NOISE ? TEXTURES_ALL : TEXTURES_IMAGE>(sc, cls, r, hit_t, hit_ref, tk, rec, sc.shade_textures, beta, stream, bounce, last, background, lds_tables,
+            const ShadeResult s = shade_path<HAS_NOISE ? TEXTURES_ALL : TEXTURES_IMAGE>(sc, cls, r, hit_t, hit_ref, tk, rec, sc.shade_textures, beta, in_sphere, stream, bounce, last, background, lds_tables,
                                                                                                  n_staged, clock);
             alive = s.alive;
             if (alive) {
@@ -639,6 +648,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
     const mirt_perlin* lds_tables = HAS_NOISE ? s_perlin : nullptr;
     // the textures shading can meet (one checker and its two colours, say), in LDS when they are few
     __shared__ mirt_texture s_textures[TEXTURES > TEXTURES_CONSTANT ? TEXTURES_STAGED : 1];
+    __shared__ unsigned long long s_scratch[PATHS_BLOCK / 64][IN_SPHERE_SCRATCH];
     const mirt_texture* textures = sc.shade_textures;
     if (TEXTURES > TEXTURES_CONSTANT && sc.n_shade_textures <= (uint32_t)TEXTURES_STAGED) {
         const uint32_t words = sc.n_shade_textures * (uint32_t)(sizeof(mirt_texture) / 4);
@@ -753,7 +763,13 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
             shade_clock.start();
             if (have && walk.finished() && !walk.confirm(sc, lds, rp.t_min, rp.t_max)) walk.begin_careful(sc, rp.t_min, rp.t_max);
             shade_clock.mark(0);
-            if (have && walk.finished()) {
+            // the samples of random_in_unit_sphere the hits of this trip will use: the whole wave works on them
+            const bool shading = have && walk.finished();
+            const bool last = bounce + 1 == rp.max_depth;
+            const uint32_t cls_now = walk.best.prim >= 0 ? ((uint32_t)walk.best.side >> walk.CLASS_SHIFT) & 7u : (uint32_t)SHADE_MISS;
+            const V3 in_sphere = random_in_unit_sphere_wave(shading && wants_in_sphere(cls_now, last), PathRng{stream, bounce + 1u, 0u},
+                                                            s_scratch[tid >> 6]);
+            if (shading) {
                 if (bounce != bounce0) ++extra_segments;
                 const HitRec h = walk.best;
                 uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS, tk = 0;
@@ -764,8 +780,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
                     hit_ref = (uint32_t)h.prim | (((uint32_t)h.side & walk.SIDE_MASK) << HIT_SIDE_SHIFT);
                     rec = TREE_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)h.prim * SHAPE_LDS_BYTES) : sc.recs + h.prim;
                 }
-                const bool last = bounce + 1 == rp.max_depth;
-                const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, stream, bounce, last, background, lds_tables, n_staged,
+                const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, in_sphere, stream, bounce, last, background, lds_tables, n_staged,
                                                            shade_clock);
                 // (the store comes last: whatever the next instructions wait for in memory, they would
                 // wait for it too)

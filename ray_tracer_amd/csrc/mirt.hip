@@ -695,7 +695,8 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     p.stack16 = scene->d.n_nodes < 65536u;
     const size_t tree = trav_nodes_bytes(scene->d.n_nodes) + (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
     const size_t fixed = (textures >= TEXTURES_ALL ? sizeof(mirt_perlin) * PERLIN_STAGED : 0) +
-                         (textures > TEXTURES_CONSTANT ? sizeof(mirt_texture) * TEXTURES_STAGED : 0);
+                         (textures > TEXTURES_CONSTANT ? sizeof(mirt_texture) * TEXTURES_STAGED : 0) +
+                         sizeof(unsigned long long) * IN_SPHERE_SCRATCH * (paths_block(textures, true) / 64);
     // tree in LDS: ONE workgroup per CU, as many waves as the registers allow, sharing one copy
     const int big = paths_block(textures, true);
     const size_t big_stack = trav_stack_bytes(p.levels, 2, big);
