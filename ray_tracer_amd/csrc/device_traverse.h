@@ -68,6 +68,12 @@ __device__ __forceinline__ f32x2 lds_read_f32x2(uint32_t addr) {
     return v;
 }
 template <int OFFSET>
+__device__ __forceinline__ double lds_read_f64(uint32_t addr) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
+    return v;
+}
+template <int OFFSET>
 __device__ __forceinline__ uint2 lds_read_u32x2(uint32_t addr) {
     unsigned long long v;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
@@ -340,7 +346,23 @@ struct RayWalk {
         --nq;
         const uint32_t index = entry & REF_INDEX_MASK;
         const uint32_t tk = (entry >> REF_KIND_SHIFT) & 7u;
-        const double* p = SHAPES_IN_LDS ? reinterpret_cast<const double*>(lds.shapes + index * SHAPE_LDS_BYTES) : sc.recs[index].f;
+        double local[9];
+        const double* p = sc.recs[SHAPES_IN_LDS ? 0u : index].f;
+        if (SHAPES_IN_LDS) {
+            // the nine parameters as nine single reads issued back to back (see lds_read_f32x2)
+            const uint32_t rec = (uint32_t)(size_t)lds.shapes + index * SHAPE_LDS_BYTES;
+            local[0] = lds_read_f64<0>(rec);
+            local[1] = lds_read_f64<8>(rec);
+            local[2] = lds_read_f64<16>(rec);
+            local[3] = lds_read_f64<24>(rec);
+            local[4] = lds_read_f64<32>(rec);
+            local[5] = lds_read_f64<40>(rec);
+            local[6] = lds_read_f64<48>(rec);
+            local[7] = lds_read_f64<56>(rec);
+            local[8] = lds_read_f64<64>(rec);
+            lds_wait();
+            p = local;
+        }
         double t;
         int side;
         if (tshape_hit(p, tk, r, dd, t_min, t_max, &t, &side)) {

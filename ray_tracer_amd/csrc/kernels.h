@@ -688,6 +688,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
     enum { PS_REFILL, PS_SHADE, PS_NODE, PS_LEAF, PS_N };
     unsigned long long ps_clk[PS_N] = {}, ps_trips[PS_N] = {}, ps_lanes[PS_N] = {};
     ShadeClock shade_clock;
+    unsigned long long ps_outer = 0;
     const unsigned long long ps_begin = __builtin_amdgcn_s_memtime();
 #define PS_START() const unsigned long long ps_t0 = __builtin_amdgcn_s_memtime()
 #define PS_STOP(k, lanes)                                                   \
@@ -702,6 +703,9 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
 #define PS_STOP(k, lanes) do {} while (0)
 #endif
     for (;;) {
+#ifdef MIRT_PATHS_STATS
+        ++ps_outer;
+#endif
         const unsigned long long need = __ballot(!have);
         // one refill serves many lanes: wait until enough are empty.  Path indices come from the
         // wave's own chunk of the queue; one global atomic fetches the next chunk.
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
         }
         atomicAdd(P.segments + 2 + 3 * PS_N, (unsigned long long)(__builtin_amdgcn_s_memtime() - ps_begin));
         for (int k = 0; k < ShadeClock::N; ++k) atomicAdd(P.segments + 3 + 3 * PS_N + k, shade_clock.clk[k]);
+        atomicAdd(P.segments + 3 + 3 * PS_N + ShadeClock::N, ps_outer);
     }
 #endif
 #undef PS_START

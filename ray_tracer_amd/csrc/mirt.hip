@@ -801,7 +801,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     // ---- per-pass state: radiance records, counters and totals in one block (kept by the
     // scene between calls), the queue pipeline's path state in arrays of this call
     const Counters C{max_depth};
-    constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
+    constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8 + 2;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
     auto round256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t radiance_bytes = round256((size_t)capacity * sizeof(double4));
     const size_t counters_bytes = round256((size_t)C.total() * sizeof(uint32_t));
@@ -943,7 +943,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
             std::fprintf(stderr, "[k_paths] %-6s %5.1f %% of wave clocks, %10.0f trips, %7.0f clocks per trip, %4.1f lanes per trip\n",
                          names[k], 100.0 * clk / total, trips, trips ? clk / trips : 0.0, trips ? lanes / trips : 0.0);
         }
-        std::fprintf(stderr, "[k_paths] other  %5.1f %%\n", 100.0 * (total - sum) / total);
+        std::fprintf(stderr, "[k_paths] other  %5.1f %%, %.0f trips of the outer loop\n", 100.0 * (total - sum) / total, (double)segments[2 + 13 + 8]);
         const char* parts[8] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "next ray / store"};
         for (int k = 0; k < 8; ++k)
             std::fprintf(stderr, "[k_paths]   shade: %-20s %5.1f %% of wave clocks\n", parts[k], 100.0 * (double)segments[2 + 13 + k] / total);
