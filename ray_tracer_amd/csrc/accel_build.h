@@ -420,10 +420,27 @@ inline BuiltTree build_fast_tree(const mirt_scene_desc* desc, const uint32_t* tk
         t.height = 1;
         return t;
     }
-    Builder b{tk, items, t.nodes, max_height};
+    std::vector<CNode> built;
+    Builder b{tk, items, built, max_height};
     const Builder::Sub top = b.build(0, desc->n_shapes, 0);
     t.root_ref = top.ref;  // node 0
     t.height = b.height_seen + 1;
+    // breadth-first order: the first k nodes are the top of the tree, which is what a kernel
+    // keeps in LDS when the whole tree does not fit
+    std::vector<uint32_t> order{0}, place(built.size(), 0);
+    for (size_t k = 0; k < order.size(); ++k)
+        for (uint32_t child : built[order[k]].child)
+            if (!(child & REF_LEAF)) {
+                place[child] = (uint32_t)order.size();
+                order.push_back(child);
+            }
+    t.nodes.resize(built.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        CNode n = built[order[k]];
+        for (uint32_t& child : n.child)
+            if (!(child & REF_LEAF)) child = place[child];
+        t.nodes[k] = n;
+    }
     return t;
 }
 

@@ -136,16 +136,22 @@ __device__ __forceinline__ Surface surface_at(const RayD& r, double t, uint32_t 
     return h;
 }
 
+// sphere_uv, hittable.rs:732-749.  A call: acos and atan2 of the library need some eighty vector
+// registers, which a kernel that merely CAN meet an image texture should not have to own.
+__device__ __noinline__ double2 sphere_uv(double nx, double ny, double nz) {
+    const double PI = 3.14159265358979323846264338327950288;
+    const double TAU = 6.28318530717958647692528676655900577;
+    const double theta = acos(-ny);
+    const double phi = atan2(-nz, nx) + PI;
+    return make_double2(phi / TAU, theta / PI);
+}
+
 // Hit::u(), Hit::v(): only image textures read them, so they are computed only there.
 __device__ __forceinline__ void surface_uv(const Surface& h, double* u, double* v) {
     if (h.kind == TK_SPHERE || h.kind == TK_MOVING_SPHERE) {
-        // sphere_uv, hittable.rs:732-749
-        const double PI = 3.14159265358979323846264338327950288;
-        const double TAU = 6.28318530717958647692528676655900577;
-        const double theta = acos(-h.outward_normal.y);
-        const double phi = atan2(-h.outward_normal.z, h.outward_normal.x) + PI;
-        *u = phi / TAU;
-        *v = theta / PI;
+        const double2 uv = sphere_uv(h.outward_normal.x, h.outward_normal.y, h.outward_normal.z);
+        *u = uv.x;
+        *v = uv.y;
     } else {
         *u = (h.ua - h.a0) / (h.a1 - h.a0);  // hittable.rs:199-200, 263-264, 327-328
         *v = (h.ub - h.b0) / (h.b1 - h.b0);
@@ -280,7 +286,7 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, const mirt_texture
                 turb = perlin_turbulence(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
             }
             const double turbulence = t->scale * h.p.z + 10.0 * turb;
-            const double c = (1.0 * 0.5) * (1.0 + sin(turbulence));
+            const double c = (1.0 * 0.5) * (1.0 + checker_sin(turbulence));
             return v3(c, c, c);
         }
         if (LEVEL < TEXTURES_IMAGE || kind != MIRT_TEX_IMAGE) break;

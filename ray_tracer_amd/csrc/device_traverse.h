@@ -103,8 +103,9 @@ enum TraverseStat : int {
 
 // Where the tree and the shapes are read from.
 struct TraverseLds {
-    const char* nodes;   // NODE_LDS_BYTES apart, or nullptr: read DScene::nodes
+    const char* nodes;   // copies of the first n_top nodes of DScene::nodes (breadth-first: the top of the tree), NODE_LDS_BYTES apart
     const char* shapes;  // SHAPE_LDS_BYTES apart, or nullptr: read DScene::recs
+    uint32_t n_top;      // NODES_IN_LDS kernels: all of them
 };
 
 // The culling slab test, f32, for the two children of a node at once.
@@ -306,16 +307,32 @@ struct RayWalk {
             c1 = refs.y;
             slab_pair(nx, fx, ny, fy, nz, fz, cull, t_lo, t_hi, &e0, &e1, &pass0, &pass1);
         } else {
-            const char* node = reinterpret_cast<const char*>(sc.nodes + cur);
-            const uint2 refs = *reinterpret_cast<const uint2*>(node + 48);
-            const f32x2 nx = *reinterpret_cast<const f32x2*>(node + cull.off[0]);
-            const f32x2 fx = *reinterpret_cast<const f32x2*>(node + (cull.off[0] ^ 8u));
-            const f32x2 ny = *reinterpret_cast<const f32x2*>(node + 16 + cull.off[1]);
-            const f32x2 fy = *reinterpret_cast<const f32x2*>(node + 16 + (cull.off[1] ^ 8u));
-            const f32x2 nz = *reinterpret_cast<const f32x2*>(node + 32 + cull.off[2]);
-            const f32x2 fz = *reinterpret_cast<const f32x2*>(node + 32 + (cull.off[2] ^ 8u));
-            c0 = refs.x;
-            c1 = refs.y;
+            // a tree too large for LDS: its top lives there, the rest is read from global memory
+            f32x2 nx, fx, ny, fy, nz, fz;
+            if (cur < lds.n_top) {
+                const uint32_t node = (uint32_t)(size_t)lds.nodes + cur * NODE_LDS_BYTES;
+                const uint32_t ax = node + cull.off[0], bx = node + (cull.off[0] ^ 8u);
+                const uint32_t ay = node + cull.off[1], by = node + (cull.off[1] ^ 8u);
+                const uint32_t az = node + cull.off[2], bz = node + (cull.off[2] ^ 8u);
+                const uint2 refs = lds_read_u32x2<48>(node);
+                nx = lds_read_f32x2<0>(ax), fx = lds_read_f32x2<0>(bx);
+                ny = lds_read_f32x2<16>(ay), fy = lds_read_f32x2<16>(by);
+                nz = lds_read_f32x2<32>(az), fz = lds_read_f32x2<32>(bz);
+                lds_wait();
+                c0 = refs.x;
+                c1 = refs.y;
+            } else {
+                const char* node = reinterpret_cast<const char*>(sc.nodes + cur);
+                const uint2 refs = *reinterpret_cast<const uint2*>(node + 48);
+                nx = *reinterpret_cast<const f32x2*>(node + cull.off[0]);
+                fx = *reinterpret_cast<const f32x2*>(node + (cull.off[0] ^ 8u));
+                ny = *reinterpret_cast<const f32x2*>(node + 16 + cull.off[1]);
+                fy = *reinterpret_cast<const f32x2*>(node + 16 + (cull.off[1] ^ 8u));
+                nz = *reinterpret_cast<const f32x2*>(node + 32 + cull.off[2]);
+                fz = *reinterpret_cast<const f32x2*>(node + 32 + (cull.off[2] ^ 8u));
+                c0 = refs.x;
+                c1 = refs.y;
+            }
             slab_pair(nx, fx, ny, fy, nz, fz, cull, t_lo, t_hi, &e0, &e1, &pass0, &pass1);
         }
         const bool leaf0 = (c0 & REF_LEAF) != 0, leaf1 = (c1 & REF_LEAF) != 0;

@@ -167,11 +167,11 @@ __host__ __device__ inline size_t trav_nodes_bytes(uint32_t n_nodes) {
 
 // Copies the tree's nodes and the shapes' traversal parameters into LDS (whole workgroup).
 template <int NTHREADS, bool NODES, bool SHAPES>
-__device__ __forceinline__ void stage_tree(const DScene& sc, char* lds_nodes, char* lds_shapes) {
+__device__ __forceinline__ void stage_tree(const DScene& sc, char* lds_nodes, char* lds_shapes, uint32_t n_top) {
     if (NODES) {
         const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.nodes);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
-        const uint32_t words = sc.n_nodes * (NODE_LDS_BYTES / 4);
+        const uint32_t words = n_top * (NODE_LDS_BYTES / 4);
         for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) dst[w] = src[w];
     }
     if (SHAPES) {
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(DScene sc, Io io, uint32_t*
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), TBLOCK);
     char* lds_shapes = lds_nodes + (NODES_IN_LDS ? trav_nodes_bytes(sc.n_nodes) : 0);
-    stage_tree<TBLOCK, NODES_IN_LDS, SHAPES_IN_LDS>(sc, lds_nodes, lds_shapes);
-    const TraverseLds lds{lds_nodes, lds_shapes};
+    stage_tree<TBLOCK, NODES_IN_LDS, SHAPES_IN_LDS>(sc, lds_nodes, lds_shapes, sc.n_nodes);
+    const TraverseLds lds{lds_nodes, lds_shapes, NODES_IN_LDS ? sc.n_nodes : 0u};
     traverse_persistent<TBLOCK, StackT, NODES_IN_LDS, SHAPES_IN_LDS, STATS>(sc, io, work_counter, t_min, t_max, lds, stack, tuning, stats);
 }
 
@@ -609,11 +609,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
 // work, and the queues' 200 bytes per path and bounce of HBM traffic buy less coherence than
 // they cost.  Results do not depend on the bounce at which this kernel takes over: a path's
 // random numbers are a function of (pixel, sample, bounce) alone.
-// Workgroup size and waves per SIMD by texture level (registers: 126 / 128 / 228 / 254 VGPRs).  With
-// the tree in LDS one workgroup fills the CU and shares one copy of the tree; without, small
-// workgroups are placed as the registers allow.
-__host__ __device__ constexpr int paths_waves(int textures) { return textures <= TEXTURES_CHECKER ? 4 : 2; }
-__host__ __device__ constexpr int paths_block(int textures, bool tree_in_lds) { return tree_in_lds ? 256 * paths_waves(textures) : 256; }
+// Workgroup size and waves per SIMD by texture level (registers: 128 / 128 / 160 / 168 VGPRs: four waves per SIMD, or three): one
+// workgroup fills the CU and shares one copy of the tree -- all of it with the shapes' records
+// (TREE_IN_LDS), or as many nodes from the top as fit.
+__host__ __device__ constexpr int paths_waves(int textures) { return textures <= TEXTURES_CHECKER ? 4 : 3; }
+__host__ __device__ constexpr int paths_block(int textures) { return 256 * paths_waves(textures); }
 // bits 0-7: as in traverse_persistent; bits 8-15: lanes waiting to be shaded that trigger
 // shading; bits 16-23: empty lanes that trigger a refill from the queue
 constexpr uint32_t PATHS_TUNING_DEFAULT = 3u | (48u << 8) | (16u << 16);
@@ -636,11 +636,12 @@ static_assert(sizeof(DScene) % 8 == 0 && sizeof(Paths) % 8 == 0 && alignof(DScen
               "k_paths finds its second and third argument at sizeof(DScene) and sizeof(DScene) + sizeof(Paths) of the argument block");
 
 template <class StackT, int TEXTURES, bool TREE_IN_LDS>
-__global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(
-    DScene sc, Paths P, RenderParams rp, uint32_t bounce0, uint32_t stack_levels, uint32_t tuning) {
-    constexpr int PATHS_BLOCK = paths_block(TEXTURES, TREE_IN_LDS);
+__global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(
+    DScene sc, Paths P, RenderParams rp, uint32_t bounce0, uint32_t stack_levels, uint32_t tuning, uint32_t n_top) {
+    constexpr int PATHS_BLOCK = paths_block(TEXTURES);
     constexpr bool HAS_NOISE = TEXTURES >= TEXTURES_ALL;
-    // dynamic LDS: [level][PATHS_BLOCK] stack entries, then (TREE_IN_LDS) nodes and shape parameters
+    // dynamic LDS: [level][PATHS_BLOCK] stack entries, the first n_top nodes of the tree (TREE_IN_LDS: all of
+    // them), and (TREE_IN_LDS) the shapes' records
     extern __shared__ __align__(16) char smem[];
     __shared__ mirt_perlin s_perlin[HAS_NOISE ? PERLIN_STAGED : 1];
     const uint32_t n_staged = HAS_NOISE && sc.perlins ? (uint32_t)PERLIN_STAGED : 0u;
@@ -660,9 +661,9 @@ __global__ __launch_bounds__(paths_block(TEXTURES, TREE_IN_LDS)) __attribute__((
     }
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
-    char* lds_shapes = lds_nodes + trav_nodes_bytes(sc.n_nodes);
-    stage_tree<PATHS_BLOCK, TREE_IN_LDS, TREE_IN_LDS>(sc, lds_nodes, lds_shapes);
-    const TraverseLds lds{lds_nodes, lds_shapes};
+    char* lds_shapes = lds_nodes + trav_nodes_bytes(n_top);
+    stage_tree<PATHS_BLOCK, true, TREE_IN_LDS>(sc, lds_nodes, lds_shapes, n_top);
+    const TraverseLds lds{lds_nodes, lds_shapes, n_top};
 
     const Counters C{rp.max_depth};
     const uint32_t n = bounce0 == 0 ? rp.n_paths : P.counters[C.live(bounce0)];

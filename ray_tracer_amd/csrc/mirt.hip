@@ -674,6 +674,7 @@ struct PathsPlan {
     int block = 256;
     size_t lds_bytes = 0;
     uint32_t levels = 1;
+    uint32_t n_top = 0;  // nodes from the top of the tree kept in LDS
     int per_cu = 1;
     const void* kernel = nullptr;
 };
@@ -693,18 +694,25 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     const int textures = scene->texture_level;
     p.levels = std::max<uint32_t>(scene->height, 1);
     p.stack16 = scene->d.n_nodes < 65536u;
-    const size_t tree = trav_nodes_bytes(scene->d.n_nodes) + (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
+    p.block = paths_block(textures);
+    const size_t nodes = trav_nodes_bytes(scene->d.n_nodes), recs = (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
     const size_t fixed = (textures >= TEXTURES_ALL ? sizeof(mirt_perlin) * PERLIN_STAGED : 0) +
                          (textures > TEXTURES_CONSTANT ? sizeof(mirt_texture) * TEXTURES_STAGED : 0) +
-                         sizeof(unsigned long long) * IN_SPHERE_SCRATCH * (paths_block(textures, true) / 64);
-    // tree in LDS: ONE workgroup per CU, as many waves as the registers allow, sharing one copy
-    const int big = paths_block(textures, true);
-    const size_t big_stack = trav_stack_bytes(p.levels, 2, big);
-    p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && big_stack + tree + fixed <= TRAV_LDS_BUDGET;
-    p.block = paths_block(textures, p.tree_in_lds);
-    p.lds_bytes = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4, p.block) + (p.tree_in_lds ? tree : 0);
-    if (p.tree_in_lds) p.kernel = paths_kernel_for<uint16_t, true>(textures);
-    else p.kernel = p.stack16 ? paths_kernel_for<uint16_t, false>(textures) : paths_kernel_for<uint32_t, false>(textures);
+                         sizeof(unsigned long long) * IN_SPHERE_SCRATCH * (p.block / 64);
+    const size_t stack = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4, p.block);
+    // ONE workgroup per CU, as many waves as the registers allow, sharing one copy of the tree: all
+    // of it and the shapes' records if they fit, else as many nodes from the top as do
+    p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && stack + nodes + recs + fixed <= TRAV_LDS_BUDGET;
+    if (p.tree_in_lds) {
+        p.n_top = scene->d.n_nodes;
+        p.lds_bytes = stack + nodes + recs;
+        p.kernel = paths_kernel_for<uint16_t, true>(textures);
+    } else {
+        const size_t room = TRAV_LDS_BUDGET > stack + fixed ? TRAV_LDS_BUDGET - stack - fixed : 0;
+        p.n_top = (uint32_t)std::min<size_t>(scene->d.n_nodes, room / NODE_LDS_BYTES);
+        p.lds_bytes = stack + trav_nodes_bytes(p.n_top);
+        p.kernel = p.stack16 ? paths_kernel_for<uint16_t, false>(textures) : paths_kernel_for<uint32_t, false>(textures);
+    }
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(p.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
@@ -730,8 +738,8 @@ hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Pa
     DScene sc = scene->d;
     Paths paths = P;
     RenderParams params = rp;
-    uint32_t levels = plan.levels, tuning = tuning_default;
-    void* args[] = {&sc, &paths, &params, &bounce, &levels, &tuning};
+    uint32_t levels = plan.levels, tuning = tuning_default, n_top = plan.n_top;
+    void* args[] = {&sc, &paths, &params, &bounce, &levels, &tuning, &n_top};
     return hipLaunchKernel(plan.kernel, dim3(grid), dim3(plan.block), args, plan.lds_bytes, stream);
 }
 
