@@ -222,9 +222,7 @@ struct RayWalk {
     static constexpr uint32_t SIDE_MASK = 15u, CLASS_SHIFT = 4, TK_SHIFT = 7;
     RayD r;
     CullRay cull;
-    double dd;
     HitRec best;
-    float t_lo;   // f32 not above t_min
     float t_hi;   // f32 not below min(t_max, best t): nothing entered beyond it can beat the best hit
     uint32_t cur;
     int sp;
@@ -252,7 +250,6 @@ struct RayWalk {
     }
 
     __device__ __forceinline__ void start(const DScene& sc, double t_min, double t_max) {
-        t_lo = f32_not_above(t_min);
         t_hi = f32_not_below(t_max);
         cur = CUR_DONE;
         sp = 0;
@@ -266,7 +263,6 @@ struct RayWalk {
 
     __device__ __forceinline__ void begin(const DScene& sc, const RayD& ray, double t_min, double t_max) {
         r = ray;
-        dd = dot(r.d, r.d);
         // a moving sphere's box holds for times inside its own span only
         cull.set(r, r.time >= sc.time_lo && r.time <= sc.time_hi);
         careful = false;
@@ -287,7 +283,9 @@ struct RayWalk {
         start(sc, t_min, t_max);
     }
 
-    __device__ __forceinline__ void node_step(const DScene& sc, const TraverseLds& lds, StackT* __restrict__ stack, uint32_t tid) {
+    // t_min: the query's (the same for every lane: its f32 lower bound lives in a scalar register)
+    __device__ __forceinline__ void node_step(const DScene& sc, const TraverseLds& lds, StackT* __restrict__ stack, uint32_t tid, double t_min) {
+        const float t_lo = f32_not_above(t_min);
         uint32_t c0, c1;
         float e0, e1;
         bool pass0, pass1;
@@ -382,7 +380,7 @@ struct RayWalk {
         }
         double t;
         int side;
-        if (tshape_hit(p, tk, r, dd, t_min, t_max, &t, &side)) {
+        if (tshape_hit(p, tk, r, dot(r.d, r.d), t_min, t_max, &t, &side)) {
             // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74)
             if (best.prim < 0 || t < best.t || (t == best.t && (int32_t)index > best.prim)) {
                 if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max)) {
@@ -527,7 +525,7 @@ __device__ __forceinline__ void traverse_persistent(const DScene& sc, Io& io, ui
                     st[STAT_NODE_ITERS] += 1;
                     st[STAT_NODE_LANES] += n_now;
                 }
-                if (active && walk.wants_node()) walk.node_step(sc, lds, stack, tid);
+                if (active && walk.wants_node()) walk.node_step(sc, lds, stack, tid, t_min);
                 n_now = __popcll(__ballot(active && walk.wants_node()));
             } while (n_now >= enough);
             if (STATS && leader()) st[STAT_CYC_NODE] += now() - t1;

@@ -677,7 +677,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     bool have = false, exhausted = false;
     uint32_t next = 0, chunk_end = 0;  // the wave's chunk of the queue (wave-uniform)
     const uint32_t chunk = chunk_rays(n, gridDim.x * (PATHS_BLOCK / 64));
-    uint32_t slot = 0, bounce = 0, extra_segments = 0;
+    uint32_t slot = 0, bounce = 0;
+    uint32_t extra_segments = 0;  // closest-hit queries of this wave beyond the first of each path (the same in every lane)
     V3 beta = v3(0.0, 0.0, 0.0);
     uint64_t stream = 0;
     RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS> walk;
@@ -774,8 +775,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             const uint32_t cls_now = walk.best.prim >= 0 ? ((uint32_t)walk.best.side >> walk.CLASS_SHIFT) & 7u : (uint32_t)SHADE_MISS;
             const V3 in_sphere = random_in_unit_sphere_wave(shading && wants_in_sphere(cls_now, last), PathRng{stream, bounce + 1u, 0u},
                                                             s_scratch[tid >> 6]);
+            extra_segments += (uint32_t)__popcll(__ballot(shading && bounce != bounce0));
             if (shading) {
-                if (bounce != bounce0) ++extra_segments;
                 const HitRec h = walk.best;
                 uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS, tk = 0;
                 const ShapeRec* rec = sc.recs;
@@ -823,13 +824,12 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             n_now = n_node;
             do {
                 PS_START();
-                if (have && walk.wants_node()) walk.node_step(sc, lds, stack, tid);
+                if (have && walk.wants_node()) walk.node_step(sc, lds, stack, tid, rp.t_min);
                 PS_STOP(PS_NODE, n_now);
                 n_now = __popcll(__ballot(have && walk.wants_node()));
             } while (n_now >= enough);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) extra_segments += __shfl_xor(extra_segments, o);
     if (lane == 0 && extra_segments) {
         // (k_accumulate counts the segments of this kernel's first bounce with those of the queues)
         atomicAdd(P.segments + 0, (unsigned long long)extra_segments);
