@@ -51,6 +51,7 @@ struct BuiltTree {
     uint32_t height = 0;  // most stack entries a traversal can hold + 1
     double time_lo = -std::numeric_limits<double>::infinity();
     double time_hi = std::numeric_limits<double>::infinity();
+    float cull_reach = std::numeric_limits<float>::infinity();
 };
 
 namespace accel {
@@ -393,12 +394,46 @@ struct Builder {
 
 }  // namespace accel
 
+// How far from the origin of the coordinates a ray may start and still be culled.
+//
+// Culling assumes that a hit the f64 shape tests accept lies on its shape up to a slack far below
+// the widening of the boxes.  For rects that holds at any distance (t = (k - o) / d is one
+// division).  The sphere's quadratic (hittable.rs:106-119) cancels: with oc = o - c its
+// discriminant b^2 - a c is a difference of two numbers near a |oc|^2, each carrying about six
+// roundings, so a ray that passes the centre at distance dist is still "hit" when
+// dist^2 - r^2 <= 12 eps |oc|^2, i.e. up to 6.7e-16 |oc|^2 / r outside the sphere.  The boxes give
+// about 1e-6 of the larger of |o| and the box's own coordinates.  With |oc| <= 2 max(|o|, B),
+// B = the largest coordinate of any box, that is enough while max(|o|, B) <= 3.7e8 r; the reach is
+// set at 2^24 r for the smallest sphere radius r (a factor of 20 in hand), and to zero -- no
+// culling at all, every shape is tested as the reference's linear list would -- when the scene
+// itself is larger than that.  Beyond the reach the reference's answer is rounding noise; it is
+// reproduced all the same.
+inline float cull_reach(const mirt_scene_desc* desc) {
+    double r_min = std::numeric_limits<double>::infinity(), b_max = 0.0;
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        const mirt_shape& s = desc->shapes[i];
+        const accel::Box b = accel::shape_box(s);
+        for (int a = 0; a < 3; ++a) {
+            if (std::isfinite(b.lo[a])) b_max = std::fmax(b_max, std::fabs(b.lo[a]));
+            if (std::isfinite(b.hi[a])) b_max = std::fmax(b_max, std::fabs(b.hi[a]));
+        }
+        if (s.kind == MIRT_SHAPE_SPHERE || s.kind == MIRT_SHAPE_MOVING_SPHERE) {
+            const double r = std::fabs(s.f[3]);
+            if (r == r) r_min = std::fmin(r_min, r);
+        }
+    }
+    const double reach = r_min * 16777216.0;  // inf without spheres
+    if (!(b_max <= reach)) return 0.0f;
+    return reach > 1.0e38 ? std::numeric_limits<float>::infinity() : (float)reach;
+}
+
 // Gates from the reference's tree, culling tree over the shapes' own boxes.
 // `tk`: per shape, TraverseKind << REF_KIND_SHIFT | ShadeClass << REF_CLASS_SHIFT.
 inline BuiltTree build_fast_tree(const mirt_scene_desc* desc, const uint32_t* tk, uint32_t max_height) {
     using namespace accel;
     BuiltTree t;
     build_gates(desc, &t);
+    t.cull_reach = cull_reach(desc);
     std::vector<Item> items(desc->n_shapes);
     for (uint32_t i = 0; i < desc->n_shapes; ++i) {
         const mirt_shape& s = desc->shapes[i];

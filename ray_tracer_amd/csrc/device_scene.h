@@ -135,6 +135,10 @@ struct DScene {
     // rays whose time lies outside [time_lo, time_hi] are not culled by boxes at all (a
     // moving sphere is boxed over its own time span only); -inf, +inf without moving shapes
     double time_lo, time_hi;
+    // ... and rays that start farther than this from the origin of the coordinates (largest
+    // component) are not culled either: see accel_build.h, cull_reach
+    float cull_reach;
+    uint32_t pad_;
 };
 
 }  // namespace mirt

@@ -205,6 +205,30 @@ __device__ __noinline__ bool gates_pass(const DGate* __restrict__ gates, const u
     return ok;
 }
 
+// The reference's own recursion (device_intersect.h, bvh_closest_reference) for ONE ray, as a call.
+// For the rays whose answer depends on the ORDER in which the reference combines its subtrees: a
+// shape test that returns a NaN t (a rect does, for a ray lying in its plane or with a NaN
+// component: hittable.rs:189-193 compares and every comparison is false) wins or loses against
+// its neighbour by position, not by value (bvh.rs:70-74), and a time that is not finite separates
+// the static sphere, which ignores it, from the moving one.  No shortcut reproduces that; nothing
+// else needs it.  The hit's side carries the shape's class and kind like a walk's own.
+__device__ __noinline__ HitRec reference_answer(const mirt_bvh_member* __restrict__ members, uint32_t n_members,
+                                                const DShape* __restrict__ shapes, uint32_t n_shapes, double ox, double oy, double oz,
+                                                double dx, double dy, double dz, double time, double t_min, double t_max) {
+    DScene sc{};
+    sc.members = members;
+    sc.n_members = n_members;
+    sc.shapes = shapes;
+    sc.n_shapes = n_shapes;
+    RayD r;
+    r.o = v3(ox, oy, oz);
+    r.d = v3(dx, dy, dz);
+    r.time = time;
+    HitRec h = bvh_closest_reference(sc, r, t_min, t_max);
+    if (h.prim >= 0) h.side = (int32_t)((uint32_t)h.side | shapes[h.prim].cls << 4 | shapes[h.prim].tk << 7);
+    return h;
+}
+
 // The walk of ONE ray (one lane) through the tree, cut into steps so that a wave can
 // choose, trip by trip, which step to run for which lanes:
 //   begin(ray)            per-ray constants of the culling test, root
@@ -214,8 +238,10 @@ __device__ __noinline__ bool gates_pass(const DGate* __restrict__ gates, const u
 //   leaf_step()           tests one parked shape
 //   finished()            neither: `best` is the closest hit (prim < 0: none) -- to be
 //                         confirmed by confirm(); if that fails, begin_careful() and walk again
+// ODDITIES: rays whose answer depends on the reference's order of evaluation (reference_answer) are
+// recognised and handed to it.
 // stack: LDS, [level][BLOCK] entries of StackT, this lane's column is `tid`.
-template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS>
+template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS, bool ODDITIES = true>
 struct RayWalk {
     // best.side of a hit found by a walk: cube side | ShadeClass << 4 | TraverseKind << 7
     // (bits 23..28 of the leaf reference, moved down as they are)
@@ -230,6 +256,7 @@ struct RayWalk {
     // of one node), kept in registers q0 (next out), q1
     uint32_t q0, q1, nq;
     bool careful;  // second walk: a hit counts only if its shape's gates pass
+    bool weird;    // a NaN t or a time that is not finite was met: see reference_answer
 
     __device__ __forceinline__ void reset() {
         cur = CUR_DONE;
@@ -238,6 +265,7 @@ struct RayWalk {
         q0 = q1 = 0;
         best = HitRec{0.0, -1, 0};
         careful = false;
+        weird = false;
     }
     __device__ __forceinline__ bool wants_node() const { return nq == 0 && cur != CUR_DONE; }
     __device__ __forceinline__ bool wants_leaf() const { return nq != 0; }
@@ -263,15 +291,26 @@ struct RayWalk {
 
     __device__ __forceinline__ void begin(const DScene& sc, const RayD& ray, double t_min, double t_max) {
         r = ray;
-        // a moving sphere's box holds for times inside its own span only
-        cull.set(r, r.time >= sc.time_lo && r.time <= sc.time_hi);
+        // a moving sphere's box holds for times inside its own span only; and the boxes say nothing
+        // about what the sphere test makes of a ray that starts too far away (accel_build.h, cull_reach)
+        const float from = fmaxf(fmaxf(__builtin_fabsf((float)r.o.x), __builtin_fabsf((float)r.o.y)), __builtin_fabsf((float)r.o.z));
+        cull.set(r, r.time >= sc.time_lo && r.time <= sc.time_hi && from <= sc.cull_reach &&
+                        r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z);
         careful = false;
+        weird = ODDITIES && !(r.time - r.time == 0.0);
         start(sc, t_min, t_max);
     }
 
     // After finished(): is `best` the reference's answer?  Nearly always the cheap test on the
     // shape's record says so; the reference's own arithmetic decides what is left.
-    __device__ __forceinline__ bool confirm(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) const {
+    __device__ __forceinline__ bool confirm(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
+        if (ODDITIES && weird) {
+            best = sc.n_members ? reference_answer(sc.members, sc.n_members, sc.shapes, sc.n_shapes, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y,
+                                                   r.d.z, r.time, t_min, t_max)
+                                : best;
+            weird = false;
+            return true;
+        }
         if (careful || best.prim < 0) return true;
         const ShapeRec* rec = SHAPES_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)best.prim * SHAPE_LDS_BYTES)
                                             : sc.recs + best.prim;
@@ -381,6 +420,7 @@ struct RayWalk {
         double t;
         int side;
         if (tshape_hit(p, tk, r, dot(r.d, r.d), t_min, t_max, &t, &side)) {
+            if (ODDITIES) weird = weird || t != t;
             // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74)
             if (best.prim < 0 || t < best.t || (t == best.t && (int32_t)index > best.prim)) {
                 if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max)) {

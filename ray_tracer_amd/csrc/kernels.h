@@ -681,7 +681,10 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     uint32_t extra_segments = 0;  // closest-hit queries of this wave beyond the first of each path (the same in every lane)
     V3 beta = v3(0.0, 0.0, 0.0);
     uint64_t stream = 0;
-    RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS> walk;
+    // (ODDITIES off: a path's rays come from the camera and from scattering, with the camera's finite time
+    // and never inside the plane of the rect they leave, so no shape test returns a NaN t; the hook for
+    // those cases costs 4 % here and is kept for caller-supplied rays, mirt_intersect)
+    RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false> walk;
     walk.reset();
     const int stay = (int)(tuning & 0xFFu), shade_at = (int)((tuning >> 8) & 0xFFu);
     const int refill_at = (int)((tuning >> 16) & 0xFFu);

@@ -366,6 +366,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     sc->d.gate_of = d_gate_of;
     sc->d.time_lo = tree.time_lo;
     sc->d.time_hi = tree.time_hi;
+    sc->d.cull_reach = tree.cull_reach;
     sc->d.members = d_members;
     sc->d.materials = d_materials;
     sc->d.textures = d_textures;

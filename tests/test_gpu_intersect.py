@@ -143,3 +143,75 @@ def test_ray_times_outside_the_shutter_and_finite_range(oracle):
             _compare(scene.hit(rays, t_min=t_min, t_max=t_max), ref, f"range ({t_min}, {t_max})")
     finally:
         scene.close()
+
+
+def _scaled_scene(scale, seed=12):
+    """The mixed scene with every length multiplied by `scale` (times untouched)."""
+    import scene_util as su
+
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for k in range(64):
+        c = rng.uniform(-20.0, 20.0, 3) * scale
+        kind = k % 5
+        if kind == 0:
+            shapes.append(su.moving_sphere(c, c + rng.uniform(-1.0, 1.0, 3) * scale, rng.uniform(0.3, 1.5) * scale, 0.0, 1.0))
+        elif kind == 1:
+            a = rng.uniform(0.5, 3.0, 2) * scale
+            shapes.append(su.shape(abi.SHAPE_XY_RECT + int(rng.integers(0, 3)), 0, c[0], c[0] + a[0], c[1], c[1] + a[1], c[2]))
+        elif kind == 2:
+            shapes.append(su.shape(abi.SHAPE_CUBE, 0, *c, *(c + rng.uniform(0.5, 3.0, 3) * scale)))
+        else:
+            shapes.append(su.sphere(*c, rng.uniform(0.3, 1.5) * scale))
+    return su.Built(shapes, seed=seed)
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1.0, 1e9, 1e25, 1e60, 1e200])
+def test_scenes_of_any_size(scale, oracle):
+    """The culling boxes are f32: a scene far outside that range (or far inside its denormals) must
+    lose speed at most, never an answer.  Rays aimed into the scene from its own scale, and the
+    same rays from very far away (|origin| up to 2^40 scene sizes)."""
+    built = _scaled_scene(scale)
+    rays = _random_rays(30_000, 8)
+    rays["origin"] *= scale
+    rays["direction"] *= scale
+    far = rays.copy()
+    far["origin"][::2] -= far["direction"][::2] * 1.0e6
+    far["origin"][1::4] -= far["direction"][1::4] * 1.0e11
+    scene = api.Scene(built.desc)
+    try:
+        for label, rs in (("near", rays), ("far", far)):
+            ref, _ = oracle.intersect(built.desc, rs, t_min=0.001, t_max=float("inf"))
+            _compare(scene.hit(rs), ref, f"scale {scale} {label}")
+        assert np.count_nonzero(oracle.intersect(built.desc, rays)[0]["prim"] >= 0) > 1000
+    finally:
+        scene.close()
+
+
+def test_degenerate_rays(oracle):
+    """Zero, infinite and NaN components in a ray: whatever the reference's arithmetic makes of them."""
+    built = _mixed_scene(seed=5)
+    rays = _random_rays(4096, 9)
+    special = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-320, 1e308, -1e308]
+    rng = np.random.default_rng(10)
+    for i in range(rays.shape[0]):
+        field = "direction" if i % 2 else "origin"
+        rays[field][i, rng.integers(0, 3)] = special[i % len(special)]
+        if i % 7 == 0:
+            rays["direction"][i, rng.integers(0, 3)] = special[(i // 7) % len(special)]
+    rays["time"][::5] = np.nan
+    scene = api.Scene(built.desc)
+    try:
+        ref, _ = oracle.intersect(built.desc, rays)
+        gpu = scene.hit(rays)
+        gpu_ref = scene.hit(rays, traversal=abi.TRAVERSE_REFERENCE)
+        # a NaN t is possible here (a rect accepts it, hittable.rs:189-191): compare bit patterns of hits' t
+        for got, label in ((gpu, "fast"), (gpu_ref, "reference-order")):
+            assert np.array_equal(got["prim"], ref["prim"]), f"{label}: {np.count_nonzero(got['prim'] != ref['prim'])} primitive ids differ"
+            hit = ref["prim"] >= 0
+            assert np.array_equal(got["side"][hit], ref["side"][hit]), label
+            assert np.array_equal(np.isnan(got["t"][hit]), np.isnan(ref["t"][hit])), label
+            ok = hit & ~np.isnan(ref["t"])
+            assert np.array_equal(got["t"][ok], ref["t"][ok]), label
+    finally:
+        scene.close()

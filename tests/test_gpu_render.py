@@ -159,3 +159,41 @@ def test_converged_images_agree_for_independent_random_streams(worlds, oracle):
     assert np.all(got <= 1.5 * floor), (got, floor)
     lum = lambda img: (img @ np.array([0.2126, 0.7152, 0.0722])).mean()
     assert abs(lum(gpu) - lum(ref_a)) <= 0.005 * lum(ref_a)
+
+
+def test_full_size_frame_properties(worlds):
+    """At the benchmark's own frame (C2: 1200x800), where the oracle would take minutes: what does
+    not depend on size.  Rendering by interleaved row tiles, by pixel ranges, in small passes and
+    by sample halves gives the bytes of the one-call render; every sample is a path (segments >=
+    samples); and half the samples twice is all of them."""
+    import torch
+
+    cfg = configs.C2
+    w, h, spp = cfg.width, cfg.height, 4
+    assert (w, h) == (1200, 800)
+    world = worlds("C1")  # the same scene as C2
+    cam = cfg.camera()
+    scene = api.Scene(world)
+    try:
+        full, st = api.render_world(cfg.background, scene, cam, w, h, spp, return_stats=True)
+        assert st["samples"] == w * h * spp and st["segments"] >= st["samples"]
+        assert full.std() > 10  # an image, not a constant
+        tiled = np.zeros_like(full)
+        for r in range(3):
+            api.render_world(cfg.background, scene, cam, w, h, spp, out=tiled, tiles=(w, 3, r))
+        assert np.array_equal(full, tiled)
+        small, st_small = api.render_world(cfg.background, scene, cam, w, h, spp, paths_per_pass=w * h, return_stats=True)
+        assert np.array_equal(full, small) and st_small["segments"] == st["segments"] and st_small["passes"] == spp
+        total = torch.zeros(w * h * 3, dtype=torch.float64, device="cuda")
+        seg = 0
+        for lo, hi in ((0, 2), (2, 4)):
+            part = torch.zeros_like(total)
+            s = api.render_accumulate(scene, cam, cfg.background, w, h, spp, part.data_ptr(), sample_range=(lo, hi))
+            seg += s["segments"]
+            total += part
+        torch.cuda.synchronize()
+        assert seg == st["segments"]
+        halves = api.resolve(total.data_ptr(), w, h, spp)
+        assert np.abs(halves.astype(int) - full.astype(int)).max() <= 1 and np.count_nonzero(halves != full) <= 20
+    finally:
+        scene.close()
