@@ -206,12 +206,12 @@ __device__ __noinline__ bool gates_pass(const DGate* __restrict__ gates, const u
 }
 
 // The reference's own recursion (device_intersect.h, bvh_closest_reference) for ONE ray, as a call.
-// For the rays whose answer depends on the ORDER in which the reference combines its subtrees: a
-// shape test that returns a NaN t (a rect does, for a ray lying in its plane or with a NaN
-// component: hittable.rs:189-193 compares and every comparison is false) wins or loses against
-// its neighbour by position, not by value (bvh.rs:70-74), and a time that is not finite separates
-// the static sphere, which ignores it, from the moving one.  No shortcut reproduces that; nothing
-// else needs it.  The hit's side carries the shape's class and kind like a walk's own.
+// For the rays whose answer is not a matter of geometry: a shape test that returns a NaN t (a rect
+// does, for a ray lying in its plane -- wherever in that plane -- or with a NaN component:
+// hittable.rs:189-193 compares and every comparison is false) wins or loses against its neighbour
+// by position in the tree, not by value (bvh.rs:70-74), and a time that is not finite separates the
+// static sphere, which ignores it, from the moving one.  No shortcut reproduces that; nothing else
+// needs it.  The hit's side carries the shape's class and kind like a walk's own.
 __device__ __noinline__ HitRec reference_answer(const mirt_bvh_member* __restrict__ members, uint32_t n_members,
                                                 const DShape* __restrict__ shapes, uint32_t n_shapes, double ox, double oy, double oz,
                                                 double dx, double dy, double dz, double time, double t_min, double t_max) {
@@ -297,8 +297,26 @@ struct RayWalk {
         cull.set(r, r.time >= sc.time_lo && r.time <= sc.time_hi && from <= sc.cull_reach &&
                         r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z);
         careful = false;
-        weird = ODDITIES && !(r.time - r.time == 0.0);
-        start(sc, t_min, t_max);
+        weird = false;
+        if (ODDITIES) {
+            // a rect "hits" a ray that lies in its plane WHEREVER the ray is ((k - o) / d = 0 / 0: a NaN
+            // passes every comparison of hittable.rs:189-193), so no box may keep such a ray away from
+            // it: rays with a zero component in their direction, or anything not finite, are not walked
+            // at all but answered by reference_answer (confirm)
+            const double product = r.d.x * r.d.y * r.d.z;
+            const double sum = ((r.o.x + r.o.y) + (r.o.z + r.d.x)) + ((r.d.y + r.d.z) + r.time);
+            weird = !(product != 0.0) || !(sum - sum == 0.0);
+        }
+        if (weird) {
+            cur = CUR_DONE;
+            sp = 0;
+            nq = 0;
+            q0 = q1 = 0;
+            best = HitRec{0.0, -1, 0};
+            t_hi = 0.0f;
+        } else {
+            start(sc, t_min, t_max);
+        }
     }
 
     // After finished(): is `best` the reference's answer?  Nearly always the cheap test on the
