@@ -801,7 +801,21 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     }
     const bool from_start = handover == 0;  // no queues of live paths, no per-path state but the radiance
 
-    const uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 26) : (1ull << 23));
+    // Default pass: 2^28 paths when the path kernel runs from the camera ray (8.6 GB of radiance
+    // records: each launch ends with a tail of a few deep paths, ~0.8 ms on RTIOW, so few large
+    // launches beat many small ones: +6.5 % over 2^26), at most a quarter of the device memory that is
+    // free; 2^23 for the queue pipeline (173 B per path).
+    uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 28) : (1ull << 23));
+    if (!o.paths_per_pass && from_start) {
+        size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+            {
+                std::lock_guard<std::mutex> lock(scene->ws_mutex);
+                free_bytes += scene->ws_bytes;  // what the scene already holds for this purpose
+            }
+            while (target > (1ull << 22) && target * sizeof(double4) > free_bytes / 4) target >>= 1;
+        }
+    }
     uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, target / n_pixels));
     const uint64_t capacity64 = (uint64_t)n_pixels * per_pass;
     if (capacity64 > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "pass of %llu paths is too large", (unsigned long long)capacity64);
