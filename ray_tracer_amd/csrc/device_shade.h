@@ -173,7 +173,23 @@ __device__ __forceinline__ uint32_t f64_as_u32(double x) {
     return (uint32_t)x;
 }
 
-// perlin.rs:52-85 + 100-122.  Tables may live in LDS or in global memory.
+// One 8-byte LDS read as exactly one ds_read_b64 (the compiler would pair neighbours into
+// ds_read2_b64, which is many times slower when the 64 lanes read 64 different places).  The
+// caller waits (lds_reads_done) before using the values.
+template <int OFFSET>
+__device__ __forceinline__ double lds_read_single_f64(uint32_t addr) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_reads_done() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// perlin.rs:52-85 + 100-122.  Tables may live in LDS (IN_LDS: the gradient vectors of four corners
+// are then fetched as twelve single reads, one wait) or in global memory.
+template <bool IN_LDS>
 __device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, const int32_t* __restrict__ perm_x,
                                                const int32_t* __restrict__ perm_y, const int32_t* __restrict__ perm_z,
                                                V3 p) {
@@ -187,6 +203,21 @@ __device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, 
 #pragma unroll
     for (int di = 0; di < 2; ++di) {
         const int32_t px = perm_x[(int32_t)((uint32_t)i + (uint32_t)di) & 255];
+        double gv[2][2][3];
+        if (IN_LDS) {
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) {
+                    const int32_t py = perm_y[(int32_t)((uint32_t)j + (uint32_t)dj) & 255];
+                    const int32_t pz = perm_z[(int32_t)((uint32_t)k + (uint32_t)dk) & 255];
+                    const uint32_t at = (uint32_t)(size_t)vecs + 24u * (uint32_t)(px ^ py ^ pz);
+                    gv[dj][dk][0] = lds_read_single_f64<0>(at);
+                    gv[dj][dk][1] = lds_read_single_f64<8>(at);
+                    gv[dj][dk][2] = lds_read_single_f64<16>(at);
+                }
+            lds_reads_done();
+        }
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
             const int32_t py = perm_y[(int32_t)((uint32_t)j + (uint32_t)dj) & 255];
@@ -194,7 +225,7 @@ __device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, 
             for (int dk = 0; dk < 2; ++dk) {
                 const int32_t pz = perm_z[(int32_t)((uint32_t)k + (uint32_t)dk) & 255];
                 const int32_t index = px ^ py ^ pz;
-                const double* __restrict__ g = vecs + 3 * index;
+                const double* __restrict__ g = IN_LDS ? gv[dj][dk] : vecs + 3 * index;
                 // weight.dot(sample): (u-i)*gx + (v-j)*gy + (w-k)*gz
                 const double color = (u - (double)di) * g[0] + (v - (double)dj) * g[1] + (w - (double)dk) * g[2];
                 // perlin.rs:112-114: i*uu + (1-i)*(1-uu) is exactly uu for i = 1 and exactly
@@ -210,6 +241,7 @@ __device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, 
 }
 
 // perlin.rs:38-50
+template <bool IN_LDS>
 __device__ __forceinline__ double perlin_turbulence(const double* __restrict__ vecs, const int32_t* __restrict__ perm_x,
                                                     const int32_t* __restrict__ perm_y,
                                                     const int32_t* __restrict__ perm_z, V3 p, int depth) {
@@ -218,7 +250,7 @@ __device__ __forceinline__ double perlin_turbulence(const double* __restrict__ v
     double accumulator = 0.0;
 #pragma nounroll
     for (int i = 0; i < depth; ++i) {
-        accumulator += weight * perlin_noise(vecs, perm_x, perm_y, perm_z, current_p);
+        accumulator += weight * perlin_noise<IN_LDS>(vecs, perm_x, perm_y, perm_z, current_p);
         weight *= 0.5;
         current_p = current_p * 2.0;
     }
@@ -280,10 +312,10 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, const mirt_texture
             double turb;
             if (t->perlin < n_staged) {
                 const mirt_perlin* pl = lds_tables + t->perlin;
-                turb = perlin_turbulence(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
+                turb = perlin_turbulence<true>(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
             } else {
                 const mirt_perlin* __restrict__ pl = sc.perlins + t->perlin;
-                turb = perlin_turbulence(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
+                turb = perlin_turbulence<false>(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
             }
             const double turbulence = t->scale * h.p.z + 10.0 * turb;
             const double c = (1.0 * 0.5) * (1.0 + checker_sin(turbulence));
