@@ -31,6 +31,28 @@ def test_render_matches_oracle(name, worlds, oracle):
     assert np.count_nonzero(diff) <= 0.002 * diff.size, f"{name}: {np.count_nonzero(diff)} of {diff.size} bytes differ"
 
 
+@pytest.mark.parametrize("name", ["Basic", "Dynamic", "Checker", "Perlin", "Earth", "SimpleLight", "CornellBox"])
+def test_reference_scenes_render_matches_oracle(name, worlds, oracle):
+    """The seven scenes of the reference's own scene table (config.rs:184-195), each under the
+    camera the reference's default configuration points at it: worlds of one to a few dozen
+    shapes, among them the one-shape world whose tree is a single leaf."""
+    w, h, spp = 64, 36, 6
+    if name == "Dynamic":
+        world = api.World.generate("Dynamic", 40, configs.WORLD_SEED, 0.0, 1.0)
+    else:
+        world = worlds(name)
+    look_from, look_at, fov = {"CornellBox": ((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 40.0)}.get(
+        name, ((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0))
+    background = api.BLACK if name in ("SimpleLight", "CornellBox") else api.SKY
+    cam = api.Camera.new(look_from, look_at, (0.0, 1.0, 0.0), fov, w / h, 0.1, 10.0, 0.0, 1.0)
+    ref_rgb, _, ctr, _ = oracle.render(world.desc, cam, background, w, h, spp)
+    gpu_rgb, stats = api.render_world(background, world, cam, w, h, spp, return_stats=True)
+    assert stats["segments"] == ctr["segments"]
+    diff = np.abs(gpu_rgb.astype(int) - ref_rgb.astype(int))
+    assert diff.max() <= 1, f"{name}: max byte difference {diff.max()}"
+    assert np.count_nonzero(diff) <= 0.002 * diff.size, f"{name}: {np.count_nonzero(diff)} of {diff.size} bytes differ"
+
+
 def test_pass_size_and_pixel_range_do_not_change_the_image(worlds):
     cfg = configs.C1
     w, h, spp = 64, 36, 6
