@@ -232,8 +232,8 @@ __device__ __noinline__ HitRec reference_answer(const mirt_bvh_member* __restric
 // The walk of ONE ray (one lane) through the tree, cut into steps so that a wave can
 // choose, trip by trip, which step to run for which lanes:
 //   begin(ray)            per-ray constants of the culling test, root
-//   wants_node()          the lane's next step is a visit of inner node `cur`
-//   wants_leaf()          the lane has parked shapes to test first
+//   wants_node()          the lane can visit inner node `cur` next
+//   wants_leaf()          the lane has parked shapes to test (PARK > 2: both may hold at once)
 //   node_step()           both children's boxes of `cur`; parks leaves; moves on or pops
 //   leaf_step()           tests one parked shape
 //   finished()            neither: `best` is the closest hit (prim < 0: none) -- to be
@@ -241,7 +241,7 @@ __device__ __noinline__ HitRec reference_answer(const mirt_bvh_member* __restric
 // ODDITIES: rays whose answer depends on the reference's order of evaluation (reference_answer) are
 // recognised and handed to it.
 // stack: LDS, [level][BLOCK] entries of StackT, this lane's column is `tid`.
-template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS, bool ODDITIES = true>
+template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS, bool ODDITIES = true, int PARK = 2>
 struct RayWalk {
     // best.side of a hit found by a walk: cube side | ShadeClass << 4 | TraverseKind << 7
     // (bits 23..28 of the leaf reference, moved down as they are)
@@ -252,9 +252,10 @@ struct RayWalk {
     float t_hi;   // f32 not below min(t_max, best t): nothing entered beyond it can beat the best hit
     uint32_t cur;
     int sp;
-    // shapes parked for the next leaf steps (leaf references), at most two (the two children
-    // of one node), kept in registers q0 (next out), q1
-    uint32_t q0, q1, nq;
+    // shapes parked for the next leaf steps (leaf references), at most PARK, in registers; q[0] is the
+    // next out.  A node step parks up to two (both children), so it needs nq <= PARK - 2: with
+    // PARK = 2 shape tests come first, with more a lane may go on visiting nodes before them
+    uint32_t q[PARK], nq;
     bool careful;  // second walk: a hit counts only if its shape's gates pass
     bool weird;    // a NaN t or a time that is not finite was met: see reference_answer
 
@@ -262,18 +263,23 @@ struct RayWalk {
         cur = CUR_DONE;
         sp = 0;
         nq = 0;
-        q0 = q1 = 0;
+        clear_parked();
         best = HitRec{0.0, -1, 0};
         careful = false;
         weird = false;
     }
-    __device__ __forceinline__ bool wants_node() const { return nq == 0 && cur != CUR_DONE; }
+    __device__ __forceinline__ bool wants_node() const { return nq <= (uint32_t)(PARK - 2) && cur != CUR_DONE; }
     __device__ __forceinline__ bool wants_leaf() const { return nq != 0; }
     __device__ __forceinline__ bool finished() const { return nq == 0 && cur == CUR_DONE; }
 
+    __device__ __forceinline__ void clear_parked() {
+#pragma unroll
+        for (int k = 0; k < PARK; ++k) q[k] = 0;
+    }
     __device__ __forceinline__ void park(uint32_t ref) {
-        q1 = q0;
-        q0 = ref;
+#pragma unroll
+        for (int k = PARK - 1; k > 0; --k) q[k] = q[k - 1];
+        q[0] = ref;
         ++nq;
     }
 
@@ -282,7 +288,7 @@ struct RayWalk {
         cur = CUR_DONE;
         sp = 0;
         nq = 0;
-        q0 = q1 = 0;
+        clear_parked();
         best = HitRec{0.0, -1, 0};
         const uint32_t root = sc.root_ref;
         if (root & REF_LEAF) park(root);  // a one-shape world: bare leaf (bvh.rs:179-180)
@@ -311,7 +317,7 @@ struct RayWalk {
             cur = CUR_DONE;
             sp = 0;
             nq = 0;
-            q0 = q1 = 0;
+            clear_parked();
             best = HitRec{0.0, -1, 0};
             t_hi = 0.0f;
         } else {
@@ -413,8 +419,9 @@ struct RayWalk {
     }
 
     __device__ __forceinline__ void leaf_step(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
-        const uint32_t entry = q0;
-        q0 = q1;
+        const uint32_t entry = q[0];
+#pragma unroll
+        for (int k = 0; k + 1 < PARK; ++k) q[k] = q[k + 1];
         --nq;
         const uint32_t index = entry & REF_INDEX_MASK;
         const uint32_t tk = (entry >> REF_KIND_SHIFT) & 7u;

@@ -614,9 +614,30 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
 // (TREE_IN_LDS), or as many nodes from the top as fit.
 __host__ __device__ constexpr int paths_waves(int textures) { return textures <= TEXTURES_CHECKER ? 4 : 3; }
 __host__ __device__ constexpr int paths_block(int textures) { return 256 * paths_waves(textures); }
-// bits 0-7: as in traverse_persistent; bits 8-15: lanes waiting to be shaded that trigger
-// shading; bits 16-23: empty lanes that trigger a refill from the queue
-constexpr uint32_t PATHS_TUNING_DEFAULT = 3u | (48u << 8) | (16u << 16);
+// Scheduling parameters of k_paths (`tuning`):
+//   bits 0-7    as in traverse_persistent
+//   bits 8-15   lanes waiting to be shaded that trigger shading
+//   bits 16-23  empty lanes that trigger a refill from the queue
+//   bits 24-29  node visits are chosen over shape tests unless 8 * (lanes wanting a shape test) >
+//               this * (lanes wanting a node visit); 0 = 8: the larger group wins
+//   bit 30      walks that ended without a hit count towards the shading trigger
+//   bit 31      such walks are finished off by the refill (the lane counts as empty)
+// Measured at 64 samples per pixel, relative to 3 | 48 << 8 | 16 << 16 | 1 << 30: bit 31 gives +12 % on
+// the textured scene (tree in LDS), -1 % on the Cornell box, -4 % on the 3,500-shape scene; a refill at
+// 24 empty lanes instead of 16 another +2.5 % on RTIOW and -2.5 % on the Cornell box.
+constexpr uint32_t PATHS_TUNING_DEFAULT = 3u | (48u << 8) | (20u << 16) | (3u << 30);
+// a tree too big for LDS: walks are long and differ in length, waiting for 48 finished lanes or 16
+// empty ones leaves the others idle for longer (3,500-shape scene: +4 %; scenes whose tree is in LDS
+// lose 1-3 % with these)
+constexpr uint32_t PATHS_TUNING_BIG_TREE = 3u | (44u << 8) | (8u << 16) | (1u << 30);
+// Shapes a walk may hold parked for later shape tests while it goes on visiting nodes: with 4 (node
+// visits allowed while at most 2 are parked) a lane can take part in whichever of the two steps the
+// wave runs next, at the price of some visits a found hit would have culled: +4 % RTIOW, +11 % Cornell
+// box, +2 % textured scene against 2 (a node visit only with none parked); 6 gains less.  With nodes
+// read from global memory the extra visits cost more than the fuller trips gain (-4 %): 2 there.
+#ifndef MIRT_PARK
+#define MIRT_PARK 4
+#endif
 
 // A kernel argument read from the argument block (constant address space: scalar loads) at byte `offset`.
 typedef const __attribute__((address_space(4))) uint32_t* KernargWords;
@@ -684,10 +705,12 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     // (ODDITIES off: a path's rays come from the camera and from scattering, with the camera's finite time
     // and never inside the plane of the rect they leave, so no shape test returns a NaN t; the hook for
     // those cases costs 4 % here and is kept for caller-supplied rays, mirt_intersect)
-    RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false> walk;
+    RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : 2> walk;
     walk.reset();
     const int stay = (int)(tuning & 0xFFu), shade_at = (int)((tuning >> 8) & 0xFFu);
     const int refill_at = (int)((tuning >> 16) & 0xFFu);
+    const int leaf_bias = ((tuning >> 24) & 63u) ? (int)((tuning >> 24) & 63u) : 8;
+    const bool count_missed = (tuning >> 30) & 1u, refill_missed = (tuning >> 31) & 1u;
 #ifdef MIRT_PATHS_STATS
     // development build: wave clocks and lane counts per piece of code, summed into P.segments[2..]
     enum { PS_REFILL, PS_SHADE, PS_NODE, PS_LEAF, PS_N };
@@ -711,11 +734,25 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
 #ifdef MIRT_PATHS_STATS
         ++ps_outer;
 #endif
-        const unsigned long long need = __ballot(!have);
+        // The wave's lanes by what they wait for (an empty lane's walk is reset: it wants nothing and holds no hit).
+        unsigned long long m_have = __ballot(have), m_node = __ballot(walk.wants_node()), m_leaf = __ballot(walk.wants_leaf());
+        unsigned long long m_hit = __ballot(walk.best.prim >= 0);
+        unsigned long long m_finished = m_have & ~(m_node | m_leaf);
+        // A walk that ended without a hit ends its path with the background (renderer.rs:114): a store,
+        // done by the refill that gives the lane its next path -- such lanes count as empty.  Shading
+        // trips are then made of hits, whose code the missed lanes would sit through idle.
+        const unsigned long long need = ~m_have | (refill_missed ? m_finished & ~m_hit : 0ull);
         // one refill serves many lanes: wait until enough are empty.  Path indices come from the
         // wave's own chunk of the queue; one global atomic fetches the next chunk.
         if (!exhausted && (__popcll(need) >= refill_at || need == ~0ull)) {
+            const bool missed = refill_missed && have && walk.finished() && walk.best.prim < 0;
             PS_START();
+            extra_segments += (uint32_t)__popcll(__ballot(missed && bounce != bounce0));
+            if (missed) {
+                store_radiance(P, slot, beta * background);
+                have = false;
+                walk.reset();
+            }
             if (next >= chunk_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(work, chunk);
@@ -758,16 +795,18 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 walk.begin(sc, r, rp.t_min, rp.t_max);
             }
             next += min((uint32_t)__popcll(need), avail);
+            m_have = __ballot(have), m_node = __ballot(walk.wants_node()), m_leaf = __ballot(walk.wants_leaf());
+            m_hit = __ballot(walk.best.prim >= 0);
+            m_finished = m_have & ~(m_node | m_leaf);
             PS_STOP(PS_REFILL, __popcll(need));
         }
-        const int n_node = __popcll(__ballot(have && walk.wants_node()));
-        const int n_leaf = __popcll(__ballot(have && walk.wants_leaf()));
-        const int n_shade = __popcll(__ballot(have && walk.finished()));
-        if (n_node + n_leaf + n_shade == 0) {
+        const int n_node = __popcll(m_node), n_leaf = __popcll(m_leaf);
+        const int n_finished = __popcll(m_finished), n_shade = __popcll(m_finished & m_hit);
+        if (n_node + n_leaf + n_finished == 0) {
             if (exhausted) break;  // no path in flight and the queue is drained
             continue;              // every lane is empty: the next trip refills
         }
-        if (n_shade >= shade_at || n_node + n_leaf == 0) {
+        if ((count_missed ? n_finished : n_shade) >= shade_at || n_node + n_leaf == 0) {
             PS_START();
             shade_clock.start();
             if (have && walk.finished() && !walk.confirm(sc, lds, rp.t_min, rp.t_max)) walk.begin_careful(sc, rp.t_min, rp.t_max);
@@ -809,11 +848,11 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 }
             }
             shade_clock.mark(7);
-            PS_STOP(PS_SHADE, n_shade);
+            PS_STOP(PS_SHADE, n_finished);
             continue;
         }
-        const int enough = max(1, ((n_node + n_leaf) * stay) >> 3);
-        if (n_leaf > n_node) {
+        const int enough = max(1, (__popcll(m_node | m_leaf) * stay) >> 3);
+        if (n_leaf * 8 > n_node * leaf_bias) {
             int n_now;
             n_now = n_leaf;
             do {

@@ -732,10 +732,11 @@ hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Pa
     const size_t want = ((size_t)expected + plan.block - 1) / plan.block;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)scene->cu_count * plan.per_cu));
     // development aid: MIRT_PATHS_TUNING overrides the scheduling parameters of the kernel
-    static const uint32_t tuning_default = [] {
+    static const uint32_t tuning_override = [] {
         const char* s = std::getenv("MIRT_PATHS_TUNING");
-        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : PATHS_TUNING_DEFAULT;
+        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : 0u;
     }();
+    const uint32_t tuning_default = tuning_override ? tuning_override : plan.tree_in_lds ? PATHS_TUNING_DEFAULT : PATHS_TUNING_BIG_TREE;
     DScene sc = scene->d;
     Paths paths = P;
     RenderParams params = rp;
