@@ -121,25 +121,32 @@ struct TraverseLds {
 // the range of f32 (d = 0, |o * inv| > 3e38) the terms become infinities of the safe sign or
 // NaN, and the max/min below drop a NaN operand: the axis then constrains nothing.
 struct CullRay {
-    float inv[3], c_near[3], c_far[3];
+    // {inv, c_near} per axis and {c_far x, c_far y}, {c_far z, -}: register pairs, so that the packed
+    // FMAs of slab_pair read one half of a pair for both their lanes and no copy is ever made
+    f32x2 ic[3], far_xy, far_z;
     uint32_t off[3];  // 8 if the ray runs down the axis (near bound = upper) else 0
     // every term finite and far from the ends of f32's range: the same constants then also
     // bound t from the other side (sure_to_cross)
     bool tame;
+    __device__ __forceinline__ float inv(int a) const { return ic[a].x; }
+    __device__ __forceinline__ float c_near(int a) const { return ic[a].y; }
+    __device__ __forceinline__ float c_far(int a) const { return a == 0 ? far_xy.x : a == 1 ? far_xy.y : far_z.x; }
     __device__ __forceinline__ void set(const RayD& r, bool cull) {
         const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
-        float size = 0.0f;
+        float size = 0.0f, far[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float i32 = __builtin_amdgcn_rcpf((float)d[a]);
             const float p = (float)o[a] * i32;
             const float e = __builtin_fabsf(p) * 0x1.0p-19f;
             size += __builtin_fabsf(i32) + __builtin_fabsf(p);
-            inv[a] = cull ? i32 : 0.0f;
-            c_near[a] = cull ? -p - e : -__builtin_inff();
-            c_far[a] = cull ? -p + e : __builtin_inff();
+            ic[a].x = cull ? i32 : 0.0f;
+            ic[a].y = cull ? -p - e : -__builtin_inff();
+            far[a] = cull ? -p + e : __builtin_inff();
             off[a] = i32 < 0.0f ? 8u : 0u;
         }
+        far_xy = (f32x2){far[0], far[1]};
+        far_z = (f32x2){far[2], 0.0f};
         tame = cull && size < 1.0e18f;  // false for a NaN
     }
     // Does the ray cross `box` ([axis][lo, hi], f32, already moved inward by the host) somewhere
@@ -152,26 +159,40 @@ struct CullRay {
         for (int a = 0; a < 3; ++a) {
             const float lo = box[2 * a], hi = box[2 * a + 1];
             const float near = off[a] ? hi : lo, far = off[a] ? lo : hi;
-            in = fmaxf(in, __builtin_fmaf(near, inv[a], c_far[a]));
-            out = fminf(out, __builtin_fmaf(far, inv[a], c_near[a]));
+            in = fmaxf(in, __builtin_fmaf(near, inv(a), c_far(a)));
+            out = fminf(out, __builtin_fmaf(far, inv(a), c_near(a)));
         }
         return tame && out > in;
     }
 };
 
 // entry / exit of both children's boxes for the t-range (t_lo, t_hi]; pass = the range is not empty.
+// Written out in instructions: the packed FMA takes the ray's constant from one half of a register
+// pair for both boxes (op_sel), and the max/min follow without the compiler's re-quieting of values
+// it did not compute itself (an FMA's result is never a signalling NaN).
 __device__ __forceinline__ void slab_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32x2 fy, f32x2 nz, f32x2 fz, const CullRay& c,
                                           float t_lo, float t_hi, float* e0, float* e1, bool* pass0, bool* pass1) {
-    const f32x2 tnx = __builtin_elementwise_fma(nx, (f32x2){c.inv[0], c.inv[0]}, (f32x2){c.c_near[0], c.c_near[0]});
-    const f32x2 tfx = __builtin_elementwise_fma(fx, (f32x2){c.inv[0], c.inv[0]}, (f32x2){c.c_far[0], c.c_far[0]});
-    const f32x2 tny = __builtin_elementwise_fma(ny, (f32x2){c.inv[1], c.inv[1]}, (f32x2){c.c_near[1], c.c_near[1]});
-    const f32x2 tfy = __builtin_elementwise_fma(fy, (f32x2){c.inv[1], c.inv[1]}, (f32x2){c.c_far[1], c.c_far[1]});
-    const f32x2 tnz = __builtin_elementwise_fma(nz, (f32x2){c.inv[2], c.inv[2]}, (f32x2){c.c_near[2], c.c_near[2]});
-    const f32x2 tfz = __builtin_elementwise_fma(fz, (f32x2){c.inv[2], c.inv[2]}, (f32x2){c.c_far[2], c.c_far[2]});
-    const float in0 = fmaxf(fmaxf(fmaxf(tnx.x, tny.x), tnz.x), t_lo);
-    const float in1 = fmaxf(fmaxf(fmaxf(tnx.y, tny.y), tnz.y), t_lo);
-    const float out0 = fminf(fminf(fminf(tfx.x, tfy.x), tfz.x), t_hi);
-    const float out1 = fminf(fminf(fminf(tfx.y, tfy.y), tfz.y), t_hi);
+    f32x2 tnx, tny, tnz, tfx, tfy, tfz;
+    asm("v_pk_fma_f32 %0, %6, %12, %12 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %7, %13, %13 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %8, %14, %14 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %3, %9, %12, %15 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %4, %10, %13, %15 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %5, %11, %14, %16 op_sel:[0,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(tnx), "=&v"(tny), "=&v"(tnz), "=&v"(tfx), "=&v"(tfy), "=&v"(tfz)
+        : "v"(nx), "v"(ny), "v"(nz), "v"(fx), "v"(fy), "v"(fz), "v"(c.ic[0]), "v"(c.ic[1]), "v"(c.ic[2]), "v"(c.far_xy), "v"(c.far_z));
+    float in0, in1, out0, out1;
+    asm("v_max_f32 %0, %4, %5\n\t"
+        "v_max_f32 %1, %7, %8\n\t"
+        "v_min_f32 %2, %10, %11\n\t"
+        "v_min_f32 %3, %13, %14\n\t"
+        "v_max3_f32 %0, %0, %6, %16\n\t"
+        "v_max3_f32 %1, %1, %9, %16\n\t"
+        "v_min3_f32 %2, %2, %12, %17\n\t"
+        "v_min3_f32 %3, %3, %15, %17"
+        : "=&v"(in0), "=&v"(in1), "=&v"(out0), "=&v"(out1)
+        : "v"(tnx.x), "v"(tny.x), "v"(tnz.x), "v"(tnx.y), "v"(tny.y), "v"(tnz.y), "v"(tfx.x), "v"(tfy.x), "v"(tfz.x), "v"(tfx.y), "v"(tfy.y),
+          "v"(tfz.y), "v"(t_lo), "v"(t_hi));
     *e0 = in0;
     *e1 = in1;
     *pass0 = !(out0 < in0);

@@ -851,7 +851,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             PS_STOP(PS_SHADE, n_finished);
             continue;
         }
-        const int enough = max(1, (__popcll(m_node | m_leaf) * stay) >> 3);
+        const int busy_share = ((int)__popcll(m_node | m_leaf) * stay) >> 3;
+        const int enough = busy_share > 1 ? busy_share : 1;
         if (n_leaf * 8 > n_node * leaf_bias) {
             int n_now;
             n_now = n_leaf;
