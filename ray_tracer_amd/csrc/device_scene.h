@@ -19,6 +19,12 @@ constexpr uint32_t REF_KIND_SHIFT = 26;
 constexpr uint32_t REF_CLASS_SHIFT = 23;
 constexpr uint32_t REF_INDEX_MASK = 0x007FFFFFu;
 constexpr uint32_t MAX_SHAPES = REF_INDEX_MASK;  // 2^23 - 1
+// A leaf reference in 16 bits, for scenes of at most REF16_MAX_SHAPES shapes: index | class << 10 |
+// kind << 13.  Never zero: every shape has a class, and SHADE_MISS = 0 is none's.
+constexpr uint32_t REF16_MAX_SHAPES = 1024, REF16_INDEX_MASK = 0x3FFu, REF16_CLASS_SHIFT = 10, REF16_KIND_SHIFT = 13;
+__host__ __device__ constexpr uint32_t ref16_of(uint32_t ref) {
+    return (ref & REF16_INDEX_MASK) | (((ref >> REF_CLASS_SHIFT) & 63u) << REF16_CLASS_SHIFT);
+}
 
 // One inner node of the culling tree (accel_build.h): the boxes of BOTH children as
 // f32, laid out so that one 8-byte read fetches the same bound of the two children and the

@@ -277,6 +277,12 @@ struct RayWalk {
     // next out.  A node step parks up to two (both children), so it needs nq <= PARK - 2: with
     // PARK = 2 shape tests come first, with more a lane may go on visiting nodes before them
     uint32_t q[PARK], nq;
+    // PACKED (nodes in LDS, PARK = 4): the parked shapes as four 16-bit references (ref16_of) in one
+    // register pair instead, lowest = next out; the LDS copy of the tree holds its leaf references in
+    // that form (stage_tree).  Parking is a shift and an or, and there is no count to keep: a reference
+    // is never zero, so the low word is zero iff nothing is parked and the high word iff at most two are.
+    static constexpr bool PACKED = NODES_IN_LDS && PARK == 4;
+    uint32_t parked_lo, parked_hi;
     bool careful;  // second walk: a hit counts only if its shape's gates pass
     bool weird;    // a NaN t or a time that is not finite was met: see reference_answer
 
@@ -289,15 +295,25 @@ struct RayWalk {
         careful = false;
         weird = false;
     }
-    __device__ __forceinline__ bool wants_node() const { return nq <= (uint32_t)(PARK - 2) && cur != CUR_DONE; }
-    __device__ __forceinline__ bool wants_leaf() const { return nq != 0; }
-    __device__ __forceinline__ bool finished() const { return nq == 0 && cur == CUR_DONE; }
+    __device__ __forceinline__ bool wants_node() const {
+        return (PACKED ? parked_hi == 0u : nq <= (uint32_t)(PARK - 2)) && cur != CUR_DONE;
+    }
+    __device__ __forceinline__ bool wants_leaf() const { return PACKED ? parked_lo != 0u : nq != 0; }
+    __device__ __forceinline__ bool finished() const { return (PACKED ? parked_lo == 0u : nq == 0) && cur == CUR_DONE; }
 
     __device__ __forceinline__ void clear_parked() {
 #pragma unroll
         for (int k = 0; k < PARK; ++k) q[k] = 0;
+        parked_lo = parked_hi = 0u;
     }
+    // ref: a leaf reference as the node it was read from holds it (PACKED: its low 16 bits are the ref16)
     __device__ __forceinline__ void park(uint32_t ref) {
+        if (PACKED) {
+            // (hi:lo) << 16 | low half of ref: a funnel shift and a byte permute
+            parked_hi = __builtin_amdgcn_alignbit(parked_hi, parked_lo, 16);
+            parked_lo = __builtin_amdgcn_perm(parked_lo, ref, 0x05040100u);
+            return;
+        }
 #pragma unroll
         for (int k = PARK - 1; k > 0; --k) q[k] = q[k - 1];
         q[0] = ref;
@@ -312,7 +328,7 @@ struct RayWalk {
         clear_parked();
         best = HitRec{0.0, -1, 0};
         const uint32_t root = sc.root_ref;
-        if (root & REF_LEAF) park(root);  // a one-shape world: bare leaf (bvh.rs:179-180)
+        if (root & REF_LEAF) park(PACKED ? ref16_of(root) : root);  // a one-shape world: bare leaf (bvh.rs:179-180)
         else cur = root;
     }
 
@@ -376,7 +392,7 @@ struct RayWalk {
         if (NODES_IN_LDS) {
             // seven 8-byte reads of one node, issued back to back, one wait
             // (LDS byte address = the low half of the generic address of an LDS object)
-            const uint32_t node = (uint32_t)(size_t)lds.nodes + cur * NODE_LDS_BYTES;
+            const uint32_t node = (uint32_t)(size_t)lds.nodes + __umul24(cur, (uint32_t)NODE_LDS_BYTES);  // (one v_mad_u32_u24)
             const uint32_t ax = node + cull.off[0], bx = node + (cull.off[0] ^ 8u);
             const uint32_t ay = node + cull.off[1], by = node + (cull.off[1] ^ 8u);
             const uint32_t az = node + cull.off[2], bz = node + (cull.off[2] ^ 8u);
@@ -392,7 +408,7 @@ struct RayWalk {
             // a tree too large for LDS: its top lives there, the rest is read from global memory
             f32x2 nx, fx, ny, fy, nz, fz;
             if (cur < lds.n_top) {
-                const uint32_t node = (uint32_t)(size_t)lds.nodes + cur * NODE_LDS_BYTES;
+                const uint32_t node = (uint32_t)(size_t)lds.nodes + __umul24(cur, (uint32_t)NODE_LDS_BYTES);  // (one v_mad_u32_u24)
                 const uint32_t ax = node + cull.off[0], bx = node + (cull.off[0] ^ 8u);
                 const uint32_t ay = node + cull.off[1], by = node + (cull.off[1] ^ 8u);
                 const uint32_t az = node + cull.off[2], bz = node + (cull.off[2] ^ 8u);
@@ -440,17 +456,28 @@ struct RayWalk {
     }
 
     __device__ __forceinline__ void leaf_step(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
-        const uint32_t entry = q[0];
+        uint32_t index, tk, class_and_kind;
+        if (PACKED) {
+            const uint32_t entry = parked_lo & 0xFFFFu;
+            parked_lo = __builtin_amdgcn_alignbit(parked_hi, parked_lo, 16);
+            parked_hi >>= 16;
+            index = entry & REF16_INDEX_MASK;
+            tk = entry >> REF16_KIND_SHIFT;
+            class_and_kind = entry >> REF16_CLASS_SHIFT;
+        } else {
+            const uint32_t entry = q[0];
 #pragma unroll
-        for (int k = 0; k + 1 < PARK; ++k) q[k] = q[k + 1];
-        --nq;
-        const uint32_t index = entry & REF_INDEX_MASK;
-        const uint32_t tk = (entry >> REF_KIND_SHIFT) & 7u;
+            for (int k = 0; k + 1 < PARK; ++k) q[k] = q[k + 1];
+            --nq;
+            index = entry & REF_INDEX_MASK;
+            tk = (entry >> REF_KIND_SHIFT) & 7u;
+            class_and_kind = (entry >> REF_CLASS_SHIFT) & 63u;
+        }
         double local[9];
         const double* p = sc.recs[SHAPES_IN_LDS ? 0u : index].f;
         if (SHAPES_IN_LDS) {
             // the nine parameters as nine single reads issued back to back (see lds_read_f32x2)
-            const uint32_t rec = (uint32_t)(size_t)lds.shapes + index * SHAPE_LDS_BYTES;
+            const uint32_t rec = (uint32_t)(size_t)lds.shapes + __umul24(index, (uint32_t)SHAPE_LDS_BYTES);
             local[0] = lds_read_f64<0>(rec);
             local[1] = lds_read_f64<8>(rec);
             local[2] = lds_read_f64<16>(rec);
@@ -470,7 +497,7 @@ struct RayWalk {
             // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74)
             if (best.prim < 0 || t < best.t || (t == best.t && (int32_t)index > best.prim)) {
                 if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max)) {
-                    best = HitRec{t, (int32_t)index, (int32_t)((uint32_t)side | ((entry >> REF_CLASS_SHIFT) & 63u) << CLASS_SHIFT)};
+                    best = HitRec{t, (int32_t)index, (int32_t)((uint32_t)side | class_and_kind << CLASS_SHIFT)};
                     t_hi = fminf(t_hi, f32_not_below(t));
                 }
             }

@@ -166,13 +166,22 @@ __host__ __device__ inline size_t trav_nodes_bytes(uint32_t n_nodes) {
 }
 
 // Copies the tree's nodes and the shapes' traversal parameters into LDS (whole workgroup).
-template <int NTHREADS, bool NODES, bool SHAPES>
+// REF16: leaf references in the copy become REF_LEAF | ref16_of(reference) (RayWalk::PACKED).
+template <int NTHREADS, bool NODES, bool SHAPES, bool REF16 = false>
 __device__ __forceinline__ void stage_tree(const DScene& sc, char* lds_nodes, char* lds_shapes, uint32_t n_top) {
     if (NODES) {
         const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.nodes);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
         const uint32_t words = n_top * (NODE_LDS_BYTES / 4);
         for (uint32_t w = threadIdx.x; w < words; w += NTHREADS) dst[w] = src[w];
+        if (REF16) {
+            __syncthreads();
+            for (uint32_t node = threadIdx.x; node < n_top; node += NTHREADS) {
+                uint32_t* child = reinterpret_cast<CNode*>(lds_nodes)[node].child;
+                if (child[0] & REF_LEAF) child[0] = REF_LEAF | ref16_of(child[0]);
+                if (child[1] & REF_LEAF) child[1] = REF_LEAF | ref16_of(child[1]);
+            }
+        }
     }
     if (SHAPES) {
         // the shapes' records, as they lie in DScene::recs
@@ -683,7 +692,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
     char* lds_shapes = lds_nodes + trav_nodes_bytes(n_top);
-    stage_tree<PATHS_BLOCK, true, TREE_IN_LDS>(sc, lds_nodes, lds_shapes, n_top);
+    typedef RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : 2> Walk;
+    stage_tree<PATHS_BLOCK, true, TREE_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
     const TraverseLds lds{lds_nodes, lds_shapes, n_top};
 
     const Counters C{rp.max_depth};
@@ -705,7 +715,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     // (ODDITIES off: a path's rays come from the camera and from scattering, with the camera's finite time
     // and never inside the plane of the rect they leave, so no shape test returns a NaN t; the hook for
     // those cases costs 4 % here and is kept for caller-supplied rays, mirt_intersect)
-    RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : 2> walk;
+    Walk walk;
     walk.reset();
     const int stay = (int)(tuning & 0xFFu), shade_at = (int)((tuning >> 8) & 0xFFu);
     const int refill_at = (int)((tuning >> 16) & 0xFFu);

@@ -703,7 +703,8 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     const size_t stack = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4, p.block);
     // ONE workgroup per CU, as many waves as the registers allow, sharing one copy of the tree: all
     // of it and the shapes' records if they fit, else as many nodes from the top as do
-    p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && stack + nodes + recs + fixed <= TRAV_LDS_BUDGET;
+    // (REF16_MAX_SHAPES: the kernel with the tree in LDS parks shapes as 16-bit references)
+    p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && scene->d.n_shapes <= REF16_MAX_SHAPES && stack + nodes + recs + fixed <= TRAV_LDS_BUDGET;
     if (p.tree_in_lds) {
         p.n_top = scene->d.n_nodes;
         p.lds_bytes = stack + nodes + recs;
