@@ -803,11 +803,11 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     }
     const bool from_start = handover == 0;  // no queues of live paths, no per-path state but the radiance
 
-    // Default pass: 2^28 paths when the path kernel runs from the camera ray (8.6 GB of radiance
+    // Default pass: 2^29 paths when the path kernel runs from the camera ray (17 GB of radiance
     // records: each launch ends with a tail of a few deep paths, ~0.8 ms on RTIOW, so few large
-    // launches beat many small ones: +6.5 % over 2^26), at most a quarter of the device memory that is
+    // launches beat many small ones: +7.5 % over 2^26), at most a quarter of the device memory that is
     // free; 2^23 for the queue pipeline (173 B per path).
-    uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 28) : (1ull << 23));
+    uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 29) : (1ull << 23));
     if (!o.paths_per_pass && from_start) {
         size_t free_bytes = 0, total_bytes = 0;
         if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
