@@ -299,6 +299,12 @@ struct RayWalk {
         return (PACKED ? parked_hi == 0u : nq <= (uint32_t)(PARK - 2)) && cur != CUR_DONE;
     }
     __device__ __forceinline__ bool wants_leaf() const { return PACKED ? parked_lo != 0u : nq != 0; }
+    // The wave's lanes that want a node visit / a shape test, as masks: one vote per comparison, combined
+    // as masks (the vote on a combined flag goes through a vector select and a second comparison).
+    __device__ __forceinline__ unsigned long long vote_node() const {
+        return __builtin_amdgcn_ballot_w64(PACKED ? parked_hi == 0u : nq <= (uint32_t)(PARK - 2)) & __builtin_amdgcn_ballot_w64(cur != CUR_DONE);
+    }
+    __device__ __forceinline__ unsigned long long vote_leaf() const { return __builtin_amdgcn_ballot_w64(PACKED ? parked_lo != 0u : nq != 0); }
     __device__ __forceinline__ bool finished() const { return (PACKED ? parked_lo == 0u : nq == 0) && cur == CUR_DONE; }
 
     __device__ __forceinline__ void clear_parked() {

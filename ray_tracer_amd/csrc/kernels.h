@@ -110,6 +110,9 @@ struct RenderParams {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+// The wave's vote as the mask the hardware already holds (HIP's __ballot goes through a vector
+// compare of the flag turned into 0 / 1: two vector instructions per vote).
+__device__ __forceinline__ unsigned long long vote(bool flag) { return __builtin_amdgcn_ballot_w64(flag); }
 
 // Three doubles into the path's 32-byte record: finished paths are scattered over the slots,
 // and a record keeps each path's result inside one 32-byte sector (three separate arrays
@@ -747,8 +750,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
         ++ps_outer;
 #endif
         // The wave's lanes by what they wait for (an empty lane's walk is reset: it wants nothing and holds no hit).
-        unsigned long long m_have = __ballot(have), m_node = __ballot(walk.wants_node()), m_leaf = __ballot(walk.wants_leaf());
-        unsigned long long m_hit = __ballot(walk.best.prim >= 0);
+        unsigned long long m_have = vote(have), m_node = walk.vote_node(), m_leaf = walk.vote_leaf();
+        unsigned long long m_hit = vote(walk.best.prim >= 0);
         unsigned long long m_finished = m_have & ~(m_node | m_leaf);
         // A walk that ended without a hit ends its path with the background (renderer.rs:114): a store,
         // done by the refill that gives the lane its next path -- such lanes count as empty.  Shading
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
         if (!exhausted && (__popcll(need) >= refill_at || need == ~0ull)) {
             const bool missed = refill_missed && have && walk.finished() && walk.best.prim < 0;
             PS_START();
-            extra_segments += (uint32_t)__popcll(__ballot(missed && bounce != bounce0));
+            extra_segments += (uint32_t)__popcll(vote(missed && bounce != bounce0));
             if (missed) {
                 store_radiance(P, slot, beta * background);
                 have = false;
@@ -807,8 +810,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 walk.begin(sc, r, rp.t_min, rp.t_max);
             }
             next += min((uint32_t)__popcll(need), avail);
-            m_have = __ballot(have), m_node = __ballot(walk.wants_node()), m_leaf = __ballot(walk.wants_leaf());
-            m_hit = __ballot(walk.best.prim >= 0);
+            m_have = vote(have), m_node = walk.vote_node(), m_leaf = walk.vote_leaf();
+            m_hit = vote(walk.best.prim >= 0);
             m_finished = m_have & ~(m_node | m_leaf);
             PS_STOP(PS_REFILL, __popcll(need));
         }
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             const uint32_t cls_now = walk.best.prim >= 0 ? ((uint32_t)walk.best.side >> walk.CLASS_SHIFT) & 7u : (uint32_t)SHADE_MISS;
             const V3 in_sphere = random_in_unit_sphere_wave(shading && wants_in_sphere(cls_now, last), PathRng{stream, bounce + 1u, 0u},
                                                             s_scratch[tid >> 6]);
-            extra_segments += (uint32_t)__popcll(__ballot(shading && bounce != bounce0));
+            extra_segments += (uint32_t)__popcll(vote(shading && bounce != bounce0));
             if (shading) {
                 const HitRec h = walk.best;
                 uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS, tk = 0;
@@ -866,22 +869,26 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
         const int busy_share = ((int)__popcll(m_node | m_leaf) * stay) >> 3;
         const int enough = busy_share > 1 ? busy_share : 1;
         if (n_leaf * 8 > n_node * leaf_bias) {
-            int n_now;
-            n_now = n_leaf;
+            // (the lane's own wish travels round the loop as a flag: evaluated once per trip, for the vote
+            // and for the next trip's branch alike)
+            int n_now = n_leaf;
+            bool wants = walk.wants_leaf();
             do {
                 PS_START();
-                if (have && walk.wants_leaf()) walk.leaf_step(sc, lds, rp.t_min, rp.t_max);
+                if (wants) walk.leaf_step(sc, lds, rp.t_min, rp.t_max);
                 PS_STOP(PS_LEAF, n_now);
-                n_now = __popcll(__ballot(have && walk.wants_leaf()));
+                wants = walk.wants_leaf();
+                n_now = __popcll(walk.vote_leaf());
             } while (n_now >= enough);
         } else {
-            int n_now;
-            n_now = n_node;
+            int n_now = n_node;
+            bool wants = walk.wants_node();
             do {
                 PS_START();
-                if (have && walk.wants_node()) walk.node_step(sc, lds, stack, tid, rp.t_min);
+                if (wants) walk.node_step(sc, lds, stack, tid, rp.t_min);
                 PS_STOP(PS_NODE, n_now);
-                n_now = __popcll(__ballot(have && walk.wants_node()));
+                wants = walk.wants_node();
+                n_now = __popcll(walk.vote_node());
             } while (n_now >= enough);
         }
     }
