@@ -12,7 +12,8 @@ rendered rows), or with --split sample every rank renders all pixels for spp/N o
 samples and the f64 accumulation images are summed with one RCCL reduce.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with
-the algorithmic bytes of DESIGN.md: the path kernel (whole paths in registers, 24 bytes of
+the bytes a queue-per-bounce pipeline moves for the same work (272 per path segment + 24
+per sample, `roofline.bytes_per_unit`): the path kernel (whole paths in registers, 24 bytes of
 radiance out per sample) in the default mode, the closest-hit kernel of the per-bounce
 pipeline with --handover -1.  Neither is bound by HBM: the path kernel saturates the vector
 ALU's issue slots (`roofline.valu_issue_busy`, measured), and `roofline.valu_f64` prices the
