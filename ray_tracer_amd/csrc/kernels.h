@@ -913,6 +913,10 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
 #undef PS_STOP
 }
 
+}  // namespace mirt
+#include "paths_regroup.h"
+namespace mirt {
+
 // ------------------------------------------------------------------ accumulate
 // pixel += color(sample) for the samples of this pass, in sample order
 // (renderer.rs:78-84), into the caller's f64 accumulation image.

@@ -741,6 +741,37 @@ hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Pa
     DScene sc = scene->d;
     Paths paths = P;
     RenderParams params = rp;
+    // development switch: MIRT_PATHS_REGROUP = number of walking waves selects the kernel that regroups
+    // paths across the waves of a workgroup (paths_regroup.h), for scenes whose tree is in LDS.  Same
+    // results; measured slower than k_paths so far (RTIOW: 3000 against 5000 Msamples/s with 10 walking
+    // waves; 3750 with 384 more paths in flight than walking lanes, MIRT_REGROUP_EXTRA, which is beyond
+    // what the kernel's argument against deadlock covers: more than 64 is at the developer's risk).
+    static const uint32_t regroup_walking = [] {
+        const char* s = std::getenv("MIRT_PATHS_REGROUP");
+        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : 0u;
+    }();
+    static const uint32_t regroup_tuning = [] {
+        const char* s = std::getenv("MIRT_REGROUP_TUNING");
+        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : (1u | (16u << 8) | (16u << 16));
+    }();
+    static const uint32_t regroup_extra = [] {
+        const char* s = std::getenv("MIRT_REGROUP_EXTRA");
+        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : 64u;
+    }();
+    if (regroup_walking && plan.tree_in_lds && bounce == 0) {
+        const int textures = scene->texture_level;
+        const void* kernel = textures == TEXTURES_CONSTANT ? (const void*)k_paths_regroup<TEXTURES_CONSTANT>
+                             : textures == TEXTURES_CHECKER ? (const void*)k_paths_regroup<TEXTURES_CHECKER>
+                             : textures == TEXTURES_IMAGE   ? (const void*)k_paths_regroup<TEXTURES_IMAGE>
+                                                            : (const void*)k_paths_regroup<TEXTURES_ALL>;
+        const size_t lds_bytes = ((plan.lds_bytes + 15) & ~(size_t)15) + regroup_ring_bytes();
+        const uint32_t waves = (uint32_t)plan.block / 64u;
+        uint32_t walking = std::min(regroup_walking, waves - 1u), n_total = walking * 64u + regroup_extra, levels = plan.levels, tuning = regroup_tuning;
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        void* args[] = {&sc, &paths, &params, &levels, &walking, &n_total, &tuning};
+        return hipLaunchKernel(kernel, dim3(grid), dim3(plan.block), args, lds_bytes, stream);
+    }
     uint32_t levels = plan.levels, tuning = tuning_default, n_top = plan.n_top;
     void* args[] = {&sc, &paths, &params, &bounce, &levels, &tuning, &n_top};
     return hipLaunchKernel(plan.kernel, dim3(grid), dim3(plan.block), args, plan.lds_bytes, stream);
