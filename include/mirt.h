@@ -302,6 +302,23 @@ int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera,
                            uint32_t spp, uint32_t max_depth, uint64_t seed,
                            const mirt_render_opts* opts, double* d_accum, mirt_stats* stats);
 
+/* mirt_render_accumulate for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arguments, same sums in d_accum bit for bit; it calls no hipMalloc / hipFree: the radiance
+ * records of a pass live in an array of MIRT_STATIC_PASS_PATHS records (+16 KB of counters) that every
+ * device the library runs on holds from load until the process ends.  Limits: the pixels selected by
+ * opts (range and tile split) must number at most MIRT_STATIC_PASS_PATHS (split larger frames into
+ * pixel ranges), use_bvh = 1 with MIRT_TRAVERSE_FAST, handover_bounce = 0, profile = 0; anything else
+ * returns MIRT_ERR_UNSUPPORTED.  Passes are at most MIRT_STATIC_PASS_PATHS paths, so a large frame
+ * takes more launches than mirt_render_accumulate gives it.  All calls on one device share the one
+ * array: calls from one process are serialised per device by the library; nothing keeps the contents
+ * between calls. */
+#define MIRT_STATIC_PASS_PATHS (1u << 20)
+int mirt_render_accumulate_static(const mirt_scene* scene, const mirt_camera* camera,
+                                  const double background[3], uint32_t width, uint32_t height,
+                                  uint32_t spp, uint32_t max_depth, uint64_t seed,
+                                  const mirt_render_opts* opts, double* d_accum, mirt_stats* stats);
+
 /* The tail of `render` + the byte cast of render_world (src/renderer.rs:85-89,
  * 42): pixel / spp, sqrt per channel, * 255.99, saturating truncation to u8
  * (NaN -> 0).  d_accum is DEVICE memory, out_rgb HOST memory; pixels

@@ -148,6 +148,7 @@ MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_DIFFUSE_LIGHT = range(4)
 TEX_CONSTANT, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(4)
 TRAVERSE_REFERENCE, TRAVERSE_FAST = 0, 1
 HANDOVER_NEVER, HANDOVER_PROBE = -1, -2
+STATIC_PASS_PATHS = 1 << 20  # MIRT_STATIC_PASS_PATHS
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = 0, -1, -2, -3, -4, -5
 
 # name -> (restype, argtypes) for every symbol the headers declare
@@ -182,6 +183,22 @@ MIRT_SYMBOLS = {
         ],
     ),
     "mirt_render_accumulate": (
+        C.c_int,
+        [
+            C.c_void_p,
+            C.POINTER(Camera),
+            C.POINTER(C.c_double),
+            C.c_uint32,
+            C.c_uint32,
+            C.c_uint32,
+            C.c_uint32,
+            C.c_uint64,
+            C.POINTER(RenderOpts),
+            C.c_void_p,
+            C.POINTER(Stats),
+        ],
+    ),
+    "mirt_render_accumulate_static": (
         C.c_int,
         [
             C.c_void_p,

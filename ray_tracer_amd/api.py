@@ -205,11 +205,13 @@ def render_world(background, world, camera, screen_width, screen_height, antiali
 
 def render_accumulate(scene, camera, background, width, height, spp, d_accum_ptr, seed=0x5EED0002, max_depth=MAX_DEPTH,
                       use_bvh=True, traversal=abi.TRAVERSE_FAST, pixel_range=(0, 0), sample_range=(0, 0),
-                      paths_per_pass=0, profile=False, tiles=(0, 1, 0), handover=(0, 0)):
-    """Adds the radiance of a sample range into a DEVICE f64 image (address `d_accum_ptr`)."""
+                      paths_per_pass=0, profile=False, tiles=(0, 1, 0), handover=(0, 0), static=False):
+    """Adds the radiance of a sample range into a DEVICE f64 image (address `d_accum_ptr`).
+    static=True goes through mirt_render_accumulate_static, the entry point that allocates nothing."""
     opts = make_opts(use_bvh, traversal, pixel_range, sample_range, paths_per_pass, profile, tiles=tiles, handover=handover)
     stats = abi.Stats()
-    _check(abi.libmirt().mirt_render_accumulate(scene.handle, C.byref(camera.c), _vec3(background), width, height, spp,
+    entry = abi.libmirt().mirt_render_accumulate_static if static else abi.libmirt().mirt_render_accumulate
+    _check(entry(scene.handle, C.byref(camera.c), _vec3(background), width, height, spp,
                                                 max_depth, seed, C.byref(opts), C.c_void_p(d_accum_ptr),
                                                 C.byref(stats)))
     return stats_dict(stats)

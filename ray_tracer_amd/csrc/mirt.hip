@@ -135,6 +135,42 @@ struct Workspace {
 };
 }  // namespace
 
+// ---- the array behind mirt_render_accumulate_static: one pass's radiance records, counters and
+// totals (the block the other entry points allocate).  Every device the library runs on holds its own
+// copy at its own address until the process ends.
+constexpr uint32_t STATIC_PASS_PATHS = MIRT_STATIC_PASS_PATHS;
+constexpr size_t STATIC_TAIL_BYTES = 16 * 1024;  // counters (at most 2551 words at depth 255) + totals
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)STATIC_PASS_PATHS * sizeof(double4) + STATIC_TAIL_BYTES;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+namespace {
+// In host code `scratch` is only a handle for hipGetSymbolAddress; kernels, memsets and copies
+// get the address it returns for the device that is current, kept here per device.
+constexpr int MAX_DEVICES = 64;
+struct ScratchOfDevice {
+    std::mutex setup;        // guards ptr
+    void* ptr = nullptr;
+    std::mutex in_use;       // one call at a time per device: the array is shared
+};
+ScratchOfDevice g_scratch[MAX_DEVICES];
+
+// Call with `device` current.  Asks the runtime once per device.
+int scratch_address(int device, void** out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(MIRT_ERR_UNSUPPORTED, "device ordinal %d is beyond %d", device, MAX_DEVICES - 1);
+    ScratchOfDevice& s = g_scratch[device];
+    std::lock_guard<std::mutex> lock(s.setup);
+    if (!s.ptr) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(MIRT_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+        s.ptr = p;
+    }
+    *out = s.ptr;
+    return MIRT_OK;
+}
+}  // namespace
+
 extern "C" {
 
 uint32_t mirt_abi_version(void) { return 1; }
@@ -242,6 +278,9 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     if ((rc = guard.enter(device)) != MIRT_OK) return rc;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+
+    void* scratch_ptr = nullptr;  // set-up for mirt_render_accumulate_static: this device's copy of the array
+    if ((rc = scratch_address(dev, &scratch_ptr)) != MIRT_OK) return rc;
 
     // ---- host-side flattening
     std::vector<DShape> shapes(desc->n_shapes);
@@ -779,7 +818,7 @@ hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Pa
 
 int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
                            uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
-                           const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {
+                           const mirt_render_opts* opts, double* d_accum, mirt_stats* stats, bool static_scratch = false) {
     if (!scene || !camera || !background || !d_accum) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
     if (width == 0 || height == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image");
     if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^31 pixels");
@@ -833,13 +872,19 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
             return fail(MIRT_ERR_INVALID_ARGUMENT, "bad handover_bounce %d", o.handover_bounce);
     }
     const bool from_start = handover == 0;  // no queues of live paths, no per-path state but the radiance
+    if (static_scratch && (!from_start || o.profile))
+        return fail(MIRT_ERR_UNSUPPORTED, "mirt_render_accumulate_static serves use_bvh = 1, MIRT_TRAVERSE_FAST, handover_bounce = 0, profile = 0 only");
+    if (static_scratch && n_pixels > STATIC_PASS_PATHS)
+        return fail(MIRT_ERR_UNSUPPORTED, "%u pixels selected, at most %u fit a pass of mirt_render_accumulate_static: split the frame into pixel ranges",
+                    n_pixels, STATIC_PASS_PATHS);
 
     // Default pass: 2^29 paths when the path kernel runs from the camera ray (17 GB of radiance
     // records: each launch ends with a tail of a few deep paths, ~0.8 ms on RTIOW, so few large
     // launches beat many small ones: +7.5 % over 2^26), at most a quarter of the device memory that is
     // free; 2^23 for the queue pipeline (173 B per path).
     uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 29) : (1ull << 23));
-    if (!o.paths_per_pass && from_start) {
+    if (static_scratch) target = std::min<uint64_t>(target, STATIC_PASS_PATHS);
+    if (!o.paths_per_pass && from_start && !static_scratch) {
         size_t free_bytes = 0, total_bytes = 0;
         if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
             {
@@ -859,18 +904,30 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     const Counters C{max_depth};
     constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8 + 2;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
     auto round256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    static_assert((256 + 255 * (SHADE_NUM_CLASSES + 1)) * sizeof(uint32_t) + 256 + N_SEGMENT_WORDS * sizeof(unsigned long long) + 256 <= STATIC_TAIL_BYTES,
+                  "counters at the largest depth and the totals fit behind the static array's records");
     const size_t radiance_bytes = round256((size_t)capacity * sizeof(double4));
     const size_t counters_bytes = round256((size_t)C.total() * sizeof(uint32_t));
     const size_t segments_bytes = round256(N_SEGMENT_WORDS * sizeof(unsigned long long));
     Workspace ws;  // declared before the stream work below ends: released after the final synchronise
-    HIP_TRY(ws.take(scene, radiance_bytes + counters_bytes + segments_bytes));
+    std::unique_lock<std::mutex> scratch_lock;  // held to the end of the call when the shared array is used
+    void* block = nullptr;
+    if (static_scratch) {
+        if (radiance_bytes + counters_bytes + segments_bytes > STATIC_SCRATCH_BYTES)
+            return fail(MIRT_ERR_UNSUPPORTED, "a pass of %u paths does not fit the static array", capacity);
+        if ((rc = scratch_address(scene->device, &block)) != MIRT_OK) return rc;
+        scratch_lock = std::unique_lock<std::mutex>(g_scratch[scene->device].in_use);
+    } else {
+        HIP_TRY(ws.take(scene, radiance_bytes + counters_bytes + segments_bytes));
+        block = ws.ptr;
+    }
     DeviceArena arena;
     Paths P;
     std::memset(&P, 0, sizeof P);
     P.capacity = capacity;
-    P.radiance = reinterpret_cast<double4*>(ws.ptr);
-    P.counters = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.ptr) + radiance_bytes);
-    P.segments = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws.ptr) + radiance_bytes + counters_bytes);
+    P.radiance = reinterpret_cast<double4*>(block);
+    P.counters = reinterpret_cast<uint32_t*>(static_cast<char*>(block) + radiance_bytes);
+    P.segments = reinterpret_cast<unsigned long long*>(static_cast<char*>(block) + radiance_bytes + counters_bytes);
     if (!from_start) {
         double** f64_arrays[] = {&P.ox, &P.oy, &P.oz, &P.dx, &P.dy, &P.dz, &P.time, &P.bx, &P.by, &P.bz, &P.hit_t};
         for (double** a : f64_arrays) HIP_TRY(arena.alloc(a, (size_t)capacity));
@@ -1035,6 +1092,12 @@ int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera, c
                            uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
                            const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {
     return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats);
+}
+
+int mirt_render_accumulate_static(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
+                                  uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
+                                  const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {
+    return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats, true);
 }
 
 int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
