@@ -333,6 +333,48 @@ int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, u
                        uint32_t pixel_begin, uint32_t pixel_end, uint32_t tile_size, uint32_t tile_count,
                        uint32_t tile_index, int device, uint8_t* out_rgb);
 
+/* ---- one frame over several devices from one process.  The reference spreads the pixels of a
+ * frame over the threads of one process (rayon, src/renderer.rs:27-43); mirt_render_multi spreads
+ * them, or the samples, over devices: one host thread drives each entry of `scenes` on that
+ * scene's device. */
+enum {
+    /* Rank r renders tiles r, r + n, r + 2n, ... of the pixel order (tile = tile_size consecutive
+     * pixels, default one image row) and copies them into out_rgb; devices exchange nothing.  The
+     * bytes are those of mirt_render on one device. */
+    MIRT_SPLIT_TILE = 0,
+    /* Rank r renders every pixel for samples [r * spp / n, (r + 1) * spp / n) into an f64 image on
+     * its device; the images are summed slice-wise (each rank sums and resolves 1/n of the pixels)
+     * and the bytes gathered into out_rgb.  f64 sums in another order than on one device: a byte
+     * may differ from mirt_render's by one level. */
+    MIRT_SPLIT_SAMPLE = 1
+};
+enum {
+    /* slices fetched with peer copies (one per xGMI link at a time) and added in rank order: the
+     * result does not depend on timing; scenes may share a device */
+    MIRT_REDUCE_PEER = 0,
+    /* ncclReduceScatter (f64, sum) of RCCL, loaded from librccl.so on first use; every scene must be
+     * on a device of its own */
+    MIRT_REDUCE_RCCL = 1
+};
+
+typedef struct mirt_multi_opts {
+    uint32_t struct_size; /* = sizeof(mirt_multi_opts) */
+    int32_t split;        /* MIRT_SPLIT_* */
+    int32_t reduce;       /* MIRT_REDUCE_*; sample split only */
+    uint32_t tile_size;   /* tile split: pixels per tile; 0 = width (one row) */
+} mirt_multi_opts;
+
+/* render_world (src/renderer.rs:9-62) on the devices of scenes[0 .. n_scenes): every entry is the
+ * SAME scene description created on the device that is to take part (mirt_scene_create(desc,
+ * device)); an entry may repeat, or several entries may share a device (they then take turns on
+ * it).  At most 16 entries.  opts: traversal, pass size, handover as for mirt_render; its pixel,
+ * sample and tile fields must be zero.  multi may be NULL (tile split).  stats: n_scenes entries,
+ * one per rank, or NULL.  out_rgb as for mirt_render. */
+int mirt_render_multi(const mirt_scene* const* scenes, uint32_t n_scenes, const mirt_camera* camera,
+                      const double background[3], uint32_t width, uint32_t height, uint32_t spp,
+                      uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
+                      const mirt_multi_opts* multi, uint8_t* out_rgb, mirt_stats* stats);
+
 /* Camera::ray (src/camera.rs:65-88) for sample `sample` of pixel `pixel`
  * (idx of renderer.rs:74-75) for n consecutive (pixel, sample) pairs starting
  * at pixel_begin/sample: the rays a render with the same seed starts from.

@@ -120,6 +120,10 @@ class RenderOpts(C.Structure):
     ]
 
 
+class MultiOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("split", C.c_int32), ("reduce", C.c_int32), ("tile_size", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64),
@@ -148,6 +152,8 @@ MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_DIFFUSE_LIGHT = range(4)
 TEX_CONSTANT, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(4)
 TRAVERSE_REFERENCE, TRAVERSE_FAST = 0, 1
 HANDOVER_NEVER, HANDOVER_PROBE = -1, -2
+SPLIT_TILE, SPLIT_SAMPLE = 0, 1
+REDUCE_PEER, REDUCE_RCCL = 0, 1
 STATIC_PASS_PATHS = 1 << 20  # MIRT_STATIC_PASS_PATHS
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = 0, -1, -2, -3, -4, -5
 
@@ -211,6 +217,24 @@ MIRT_SYMBOLS = {
             C.c_uint64,
             C.POINTER(RenderOpts),
             C.c_void_p,
+            C.POINTER(Stats),
+        ],
+    ),
+    "mirt_render_multi": (
+        C.c_int,
+        [
+            C.POINTER(C.c_void_p),
+            C.c_uint32,
+            C.POINTER(Camera),
+            C.POINTER(C.c_double),
+            C.c_uint32,
+            C.c_uint32,
+            C.c_uint32,
+            C.c_uint32,
+            C.c_uint64,
+            C.POINTER(RenderOpts),
+            C.POINTER(MultiOpts),
+            C.POINTER(C.c_uint8),
             C.POINTER(Stats),
         ],
     ),

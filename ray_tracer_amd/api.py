@@ -203,6 +203,26 @@ def render_world(background, world, camera, screen_width, screen_height, antiali
     return (out, stats_dict(stats)) if return_stats else out
 
 
+def render_world_multi(background, scenes, camera, screen_width, screen_height, antialias_iterations, split="tile",
+                       reduce="peer", tile_size=0, seed=0x5EED0002, max_depth=MAX_DEPTH, paths_per_pass=0, out=None,
+                       return_stats=False, handover=(0, 0)):
+    """render_world over several devices from this process (mirt_render_multi): `scenes` = one Scene per
+    rank, each on the device it was created on (entries may repeat or share a device)."""
+    n = len(scenes)
+    if out is None:
+        out = np.zeros((screen_height, screen_width, 3), dtype=np.uint8)
+    assert out.dtype == np.uint8 and out.size == screen_width * screen_height * 3 and out.flags.c_contiguous
+    handles = (C.c_void_p * n)(*[s.handle for s in scenes])
+    opts = make_opts(paths_per_pass=paths_per_pass, handover=handover)
+    multi = abi.MultiOpts(C.sizeof(abi.MultiOpts), {"tile": abi.SPLIT_TILE, "sample": abi.SPLIT_SAMPLE}[split],
+                          {"peer": abi.REDUCE_PEER, "rccl": abi.REDUCE_RCCL}[reduce], tile_size)
+    stats = (abi.Stats * n)()
+    _check(abi.libmirt().mirt_render_multi(handles, n, C.byref(camera.c), _vec3(background), screen_width, screen_height,
+                                           antialias_iterations, max_depth, seed, C.byref(opts), C.byref(multi),
+                                           out.ctypes.data_as(C.POINTER(C.c_uint8)), stats))
+    return (out, [stats_dict(s) for s in stats]) if return_stats else out
+
+
 def render_accumulate(scene, camera, background, width, height, spp, d_accum_ptr, seed=0x5EED0002, max_depth=MAX_DEPTH,
                       use_bvh=True, traversal=abi.TRAVERSE_FAST, pixel_range=(0, 0), sample_range=(0, 0),
                       paths_per_pass=0, profile=False, tiles=(0, 1, 0), handover=(0, 0), static=False):

@@ -1187,3 +1187,5 @@ int mirt_render(const mirt_scene* scene, const mirt_camera* camera, const double
 }
 
 }  // extern "C"
+
+#include "multi_device.h"

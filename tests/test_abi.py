@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
     structs = {"mirt_shape": abi.Shape, "mirt_material": abi.Material, "mirt_texture": abi.Texture,
                "mirt_perlin": abi.Perlin, "mirt_image": abi.Image, "mirt_bvh_member": abi.BvhMember,
                "mirt_scene_desc": abi.SceneDesc, "mirt_camera": abi.Camera, "mirt_ray": abi.Ray, "mirt_hit": abi.Hit,
-               "mirt_render_opts": abi.RenderOpts, "mirt_stats": abi.Stats}
+               "mirt_render_opts": abi.RenderOpts, "mirt_stats": abi.Stats, "mirt_multi_opts": abi.MultiOpts}
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "mirt.h"\nint main(void) {\n' +
                    "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in structs) + "  return 0;\n}\n")

@@ -1,0 +1,95 @@
+"""mirt_render_multi: one frame over several devices from one process, as the reference
+spreads a frame over the threads of one process (src/renderer.rs:27-43).  The box has one
+GPU, so the device list repeats it: ranks {0, 0, 0} take turns on the device and exercise the
+partitioning, the concurrent host threads, the slice-wise sum and the gather."""
+import numpy as np
+import pytest
+
+from ray_tracer_amd import _abi as abi
+from ray_tracer_amd import api, configs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,frame", [("C1", (96, 54, 8)), ("C4", (50, 47, 6)), ("C5", (80, 45, 4))])
+def test_virtual_ranks_reassemble_the_single_device_image(name, frame, worlds):
+    cfg = configs.ALL[name]
+    w, h, spp = frame
+    world = worlds(name)
+    cam = cfg.camera(w, h)
+    scene = api.Scene(world)
+    other = api.Scene(world)  # a second scene object on the same device
+    try:
+        full, st = api.render_world(cfg.background, scene, cam, w, h, spp, return_stats=True)
+        for scenes in ([scene], [scene, scene, scene], [scene, other], [scene, other, scene, other, scene, other, scene, other]):
+            n = len(scenes)
+            # tile split: the same bytes, whatever the tile size
+            for tile_size in (0, 100, 7):
+                img, sts = api.render_world_multi(cfg.background, scenes, cam, w, h, spp, split="tile", tile_size=tile_size,
+                                                  return_stats=True)
+                assert np.array_equal(img, full), (n, tile_size)
+                assert sum(s["segments"] for s in sts) == st["segments"] and sum(s["samples"] for s in sts) == w * h * spp
+            # sample split: f64 sums in another order, a byte may move by one level
+            img, sts = api.render_world_multi(cfg.background, scenes, cam, w, h, spp, split="sample", return_stats=True)
+            assert sum(s["segments"] for s in sts) == st["segments"]
+            diff = np.abs(img.astype(int) - full.astype(int))
+            assert diff.max() <= 1 and np.count_nonzero(diff) <= max(2, 0.001 * diff.size), (n, diff.max(), np.count_nonzero(diff))
+            # and it is deterministic: peer sums run in rank order
+            again = api.render_world_multi(cfg.background, scenes, cam, w, h, spp, split="sample")
+            assert np.array_equal(img, again)
+    finally:
+        scene.close()
+        other.close()
+
+
+def test_more_ranks_than_samples_and_ragged_slices(worlds):
+    cfg = configs.C1
+    w, h, spp = 31, 17, 2  # 527 pixels: not a multiple of 3 or 4
+    world = worlds("C1")
+    cam = cfg.camera(w, h)
+    scene = api.Scene(world)
+    try:
+        full = api.render_world(cfg.background, scene, cam, w, h, spp)
+        for n in (3, 4):  # 4 ranks, 2 samples: two ranks render nothing and still take part in the sum
+            img = api.render_world_multi(cfg.background, [scene] * n, cam, w, h, spp, split="sample")
+            assert np.abs(img.astype(int) - full.astype(int)).max() <= 1
+            assert np.array_equal(api.render_world_multi(cfg.background, [scene] * n, cam, w, h, spp), full)
+    finally:
+        scene.close()
+
+
+def test_rccl_reduce_scatter_is_linked_and_refuses_shared_devices(worlds):
+    """With one GPU the RCCL path can only run as a communicator of one rank: that proves librccl
+    loads, ncclCommInitAll and ncclReduceScatter run and the slice is resolved from its result."""
+    cfg = configs.C1
+    w, h, spp = 64, 36, 4
+    world = worlds("C1")
+    cam = cfg.camera(w, h)
+    scene = api.Scene(world)
+    try:
+        full = api.render_world(cfg.background, scene, cam, w, h, spp)
+        img = api.render_world_multi(cfg.background, [scene], cam, w, h, spp, split="sample", reduce="rccl")
+        assert np.array_equal(img, full)  # one rank: the same sums in the same order
+        with pytest.raises(api.MirtError) as err:
+            api.render_world_multi(cfg.background, [scene, scene], cam, w, h, spp, split="sample", reduce="rccl")
+        assert err.value.status == abi.ERR_UNSUPPORTED
+    finally:
+        scene.close()
+
+
+def test_bad_arguments_are_refused(worlds):
+    cfg = configs.C1
+    scene = api.Scene(worlds("C1"))
+    try:
+        cam = cfg.camera(32, 18)
+        with pytest.raises(api.MirtError):
+            api.render_world_multi(cfg.background, [scene] * 17, cam, 32, 18, 1)
+        out = np.zeros((18, 32, 3), dtype=np.uint8)
+        import ctypes as C
+        handles = (C.c_void_p * 1)(scene.handle)
+        opts = api.make_opts(pixel_range=(0, 10))
+        rc = abi.libmirt().mirt_render_multi(handles, 1, C.byref(cam.c), api._vec3(cfg.background), 32, 18, 1, 50, 1,
+                                             C.byref(opts), None, out.ctypes.data_as(C.POINTER(C.c_uint8)), None)
+        assert rc == abi.ERR_INVALID_ARGUMENT
+    finally:
+        scene.close()
