@@ -58,6 +58,11 @@ def parse_args():
                          "bounce below bounce N, -1 = launches per bounce throughout, -2 = probe")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work to spend on the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collectives between the ranks: nccl (RCCL over xGMI, one GPU per rank) or gloo (host memory; ranks "
+                         "may then share a GPU: rank r uses device r mod the number of devices -- a rehearsal on a smaller box)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 from ONE process through mirt_render_multi (one host thread per device) instead of one process per GPU")
     return ap.parse_args()
 
 
@@ -87,14 +92,31 @@ def cpu_baseline(cfg, world, seconds):
     }
 
 
+def launch_ranks(n):
+    """python bench.py --gpus N from a plain shell: the same command under torch.distributed.run,
+    N child processes (this process has not initialised a GPU and only waits)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.single_process:
+        world_size = 1
+    elif "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started from a plain shell: one fresh process per GPU, before this one has touched a GPU
+        raise SystemExit(launch_ranks(args.gpus))
+    elif world_size != args.gpus:
         args.gpus = world_size
 
     import torch
@@ -104,13 +126,26 @@ def main():
 
     if not torch.cuda.is_available() or api.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: no HIP device visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_devices = api.device_count()
+    if args.backend == "nccl" and not args.single_process and local_rank >= n_devices:
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this box ({n_devices} visible); --backend gloo lets ranks share one")
+    device_index = local_rank % n_devices
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where tensors handed to collectives live
     gloo = None
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
-        gloo = dist.new_group(backend="gloo")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+            gloo = dist.new_group(backend="gloo")
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    n_ranks = args.gpus if args.single_process else world_size  # shares the frame is cut into
+    if args.split == "sample" and n_ranks > 1:
+        probe = configs.ALL[args.config]
+        if (args.spp or probe.spp) < n_ranks:
+            raise SystemExit(f"--split sample needs at least one sample per rank: spp {(args.spp or probe.spp)} < {n_ranks} ranks")
 
     cfg = configs.ALL[args.config]
     if args.spp or args.width or args.height:
@@ -119,6 +154,10 @@ def main():
     world = cfg.world()
     cam = cfg.camera()
     scene = api.Scene(world)  # scene resident in HBM before the timed region
+    rank_scenes = [scene]
+    if args.single_process and args.gpus > 1:
+        # one scene per rank, on device r (on a box with fewer devices the ranks share them)
+        rank_scenes = [scene if r % n_devices == device_index else api.Scene(world, device=r % n_devices) for r in range(args.gpus)]
     profile = not args.no_profile
 
     out = np.zeros((H, W, 3), dtype=np.uint8)
@@ -132,6 +171,13 @@ def main():
             torch.cuda.synchronize()
 
     def step():
+        if len(rank_scenes) > 1:
+            _, sts = api.render_world_multi(cfg.background, rank_scenes, cam, W, H, spp, split=args.split, paths_per_pass=args.paths_per_pass,
+                                            out=out, return_stats=True, handover=(args.handover, 0))
+            st = dict(sts[0])
+            for k in ("samples", "segments", "segments_paths", "launches_extend", "launches_paths"):
+                st[k] = sum(x[k] for x in sts)
+            return st
         if args.split == "tile" or world_size == 1:
             # rows interleaved over ranks: tile = one row, rank r owns rows r, r + N, ...
             _, st = api.render_world(cfg.background, scene, cam, W, H, spp, paths_per_pass=args.paths_per_pass,
@@ -140,10 +186,16 @@ def main():
             distributed.gather_rows(out, rank, world_size, group=gloo)
         else:
             accum.zero_()
-            lo, hi = distributed.sample_range(spp, rank, world_size)
+            lo, hi = distributed.sample_range(spp, rank, world_size)  # (never empty: spp >= ranks was checked)
             st = api.render_accumulate(scene, cam, cfg.background, W, H, spp, accum.data_ptr(), sample_range=(lo, hi),
                                        paths_per_pass=args.paths_per_pass, profile=profile, handover=(args.handover, 0))
-            distributed.reduce_accum(accum)  # RCCL over xGMI
+            if args.backend == "nccl":
+                distributed.reduce_accum(accum)  # RCCL over xGMI
+            else:
+                host = accum.cpu()
+                distributed.reduce_accum(host)
+                if rank == 0:
+                    accum.copy_(host)
             if rank == 0:
                 api.resolve(accum.data_ptr(), W, H, spp, out=out)
         return st
@@ -157,16 +209,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # sums over ranks of what each rank's library calls report
     keys = ("samples", "segments", "segments_paths", "launches_extend", "launches_paths", "ms_extend", "ms_shade", "ms_bin",
             "ms_raygen", "ms_accumulate", "ms_paths")
-    local = torch.tensor([sum(st[k] for st in step_stats) for k in keys], dtype=torch.float64, device=dev)
+    local = torch.tensor([sum(st[k] for st in step_stats) for k in keys], dtype=torch.float64, device=cdev)
     dominant = "ms_paths" if step_stats[-1]["handover_bounce"] == 0 else "ms_extend"
-    local_max_extend = torch.tensor([sum(st[dominant] for st in step_stats)], dtype=torch.float64, device=dev)
+    local_max_extend = torch.tensor([sum(st[dominant] for st in step_stats)], dtype=torch.float64, device=cdev)
     if world_size > 1:
         dist.all_reduce(local, op=dist.ReduceOp.SUM)
         dist.all_reduce(local_max_extend, op=dist.ReduceOp.MAX)
@@ -181,7 +233,7 @@ def main():
                       else f"Msamples/s (camera paths x spp per second), {cfg.name}",
             "value": value,
             "unit": "Msamples/s",
-            "n_gpus": world_size,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
@@ -194,7 +246,11 @@ def main():
                 "workload": cfg.name,
                 "width": W, "height": H, "spp": spp, "max_depth": api.MAX_DEPTH,
                 "shapes": world.n_shapes, "bvh_members": world.n_nodes,
-                "split": args.split if world_size > 1 else "none",
+                "split": args.split if n_ranks > 1 else "none",
+                "ranks": ("one process, one host thread per device (mirt_render_multi)" if args.single_process and n_ranks > 1
+                          else "one process per GPU (torch.distributed)" if n_ranks > 1 else "one"),
+                "collectives": args.backend if world_size > 1 else "none",
+                "devices_visible": n_devices,
                 "traversal": "fast (f32 culling tree, near-first, distance-pruned; reference boxes decide which hits count)",
             },
             "handover": {"bounce": int(step_stats[-1]["handover_bounce"]),
@@ -221,21 +277,34 @@ def main():
                 "units_per_launch": {"segments": tot["segments_paths"] / launches, "samples": samples / launches},
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
-                "note": "algorithmic bytes = what a queue-per-bounce pipeline moves through HBM for these segments (ray 56 + hit "
-                        "16 + path state 88 in, 88 out + two queue indices 8 = 272 B per segment, 24 B per sample); this kernel keeps "
-                        "all of it in registers, so `traffic` (measured) is far below it and the kernel is bound by vector-"
-                        "instruction issue (valu_issue_busy, from the PMC passes under profiles/), not by HBM",
+                "note": "`achieved`/`frac` are a pipeline-equivalent figure, not a utilisation: the bytes a queue-per-bounce "
+                        "pipeline moves through HBM for these segments (ray 56 + hit 16 + path state 88 in, 88 out + two queue "
+                        "indices 8 = 272 B per segment, 24 B per sample) per second of this kernel, which keeps all of it in "
+                        "registers.  What the kernel really uses: `traffic` / `hbm_frac_measured` (HBM, measured) and "
+                        "`issue_frac` = valu_issue_busy x lanes / 64 (share of the vector ALU's lane slots doing work: the "
+                        "limiting resource)",
             }
-            # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 runs of this
-            # same workload, committed under profiles/), scaled to this run's paths per launch
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_paths.json")
-            if args.config == "C2" and os.path.exists(pmc_path):
+            # Measured side of the same kernel, from the PMC passes of this workload committed under profiles/
+            # (separate rocprofv3 --pmc runs; per path, scaled to this run's paths per launch): HBM traffic
+            # (FETCH_SIZE, WRITE_SIZE) and how busy the vector ALU's issue slots are with how many lanes.
+            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_pmc_{args.config}.json") for tag in ("r02", "r01"))
+                             if os.path.exists(q)), None)
+            if pmc_path is None and args.config == "C2":
+                pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_paths.json")
+            if pmc_path and os.path.exists(pmc_path):
                 with open(pmc_path) as f:
                     pmc = json.load(f)
-                result["roofline"]["traffic"] = pmc["hbm_bytes_per_path"] * samples / launches
-                result["roofline"]["valu_issue_busy"] = pmc.get("valu_issue_busy_share_of_simd_cycles")
-                result["roofline"]["lanes_active_per_valu_instruction"] = pmc.get("lanes_active_per_valu_instruction")
-                result["roofline"]["traffic_source"] = "profiles/r01_pmc_k_paths.json (bytes per path x paths per launch)"
+                roof = result["roofline"]
+                roof["traffic"] = pmc["hbm_bytes_per_path"] * samples / launches
+                roof["hbm_frac_measured"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                busy = pmc.get("valu_issue_busy_share_of_simd_cycles")
+                lanes = pmc.get("lanes_active_per_valu_instruction")
+                roof["valu_issue_busy"] = busy
+                roof["lanes_active_per_valu_instruction"] = lanes
+                if busy is not None and lanes is not None:
+                    roof["issue_frac"] = busy * lanes / 64.0
+                    roof["limiting_resource"] = "valu_issue"
+                roof["traffic_source"] = os.path.relpath(pmc_path, ROOT) + " (counters per path x paths per launch)"
         elif profile and tot["ms_extend"] > 0:
             launches = tot["launches_extend"]
             avg_ms = tot["ms_extend"] / launches
@@ -275,7 +344,8 @@ def main():
                 result["roofline"]["valu_f64"]["frac"] = result["roofline"]["valu_f64"]["achieved_tops"] / FP64_VALU_PEAK_TOPS
         print(json.dumps(result))
 
-    scene.close()
+    for sc in set(rank_scenes):
+        sc.close()
     if world_size > 1:
         dist.destroy_process_group()
 

@@ -115,7 +115,9 @@ typedef struct mirt_image {
 
 /* One `BVHMember` (src/bvh.rs:93-101) in the reference's own order:
  * post-order, children before parents, root LAST (src/bvh.rs:33-35,130-131).
- * A leaf carries no box.  `shape` indexes the BVH-sorted shape array. */
+ * A leaf carries no box.  `shape` indexes the BVH-sorted shape array: the leaves hold shapes
+ * 0, 1, 2, ... from left to right, as the reference's build leaves them (mirt_scene_create
+ * refuses any other order: ties between equal t go by it, bvh.rs:70-74). */
 typedef struct mirt_bvh_member {
     uint32_t is_leaf;
     uint32_t left;   /* node: index of left member */
@@ -268,6 +270,11 @@ int mirt_device_count(void);
  * (src/bvh.rs:11-27): the sorted shapes and the member array. */
 int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out);
 void mirt_scene_destroy(mirt_scene* scene);
+
+/* Frees the per-pass buffers a render call left with the scene for the next one (by default up to
+ * 17 GB, see mirt_render_opts.paths_per_pass); the next render call allocates them again.  For
+ * processes that hold several scenes or need the device memory for something else between frames. */
+int mirt_scene_trim(mirt_scene* scene);
 
 /* Closest hit of each of `n` rays: Hittable::hit(&ray, t_min, t_max) on the
  * BVH (use_bvh != 0; src/bvh.rs:83-86) or on the linear shape list

@@ -770,15 +770,31 @@ int oracle_intersect(const mirt_scene_desc* desc, const mirt_ray* rays, size_t n
     if (!desc || !rays || !hits) return -1;
     if (use_bvh && (!desc->nodes || desc->n_nodes == 0)) return -1;
     Scene sc{desc};
-    tl_counters = Counters();
-    for (size_t r = 0; r < n; ++r) {
-        Ray ray(Vec3(rays[r].origin), Vec3(rays[r].direction), rays[r].time);
-        std::optional<Hit> h = world_hit(sc, use_bvh != 0, ray, t_min, t_max);
-        hits[r].prim = h ? h->prim : -1;
-        hits[r].side = h ? h->side : 0;
-        hits[r].t = h ? h->t : 0.0;
+    Counters total;
+    // rays are independent: all cores for large batches (the answers do not depend on the split)
+#pragma omp parallel if (n >= 4096)
+    {
+        tl_counters = Counters();
+#pragma omp for schedule(dynamic, 1024)
+        for (int64_t r = 0; r < (int64_t)n; ++r) {
+            Ray ray(Vec3(rays[r].origin), Vec3(rays[r].direction), rays[r].time);
+            std::optional<Hit> h = world_hit(sc, use_bvh != 0, ray, t_min, t_max);
+            hits[r].prim = h ? h->prim : -1;
+            hits[r].side = h ? h->side : 0;
+            hits[r].t = h ? h->t : 0.0;
+        }
+#pragma omp critical
+        {
+            total.segments += tl_counters.segments;
+            total.box_tests += tl_counters.box_tests;
+            total.leaf_tests += tl_counters.leaf_tests;
+            total.sphere_tests += tl_counters.sphere_tests;
+            total.rect_tests += tl_counters.rect_tests;
+            total.shaded += tl_counters.shaded;
+            total.noise_evals += tl_counters.noise_evals;
+        }
     }
-    counters_out(tl_counters, counters);
+    counters_out(total, counters);
     return 0;
 }
 
@@ -1022,11 +1038,43 @@ int64_t oracle_trace_rays(const mirt_scene_desc* desc, const mirt_camera* cam, c
     if (!desc || !cam || !pixels || !rays || !hits) return -1;
     Scene sc{desc};
     Vec3 bg(background);
-    TraceSink sink{rays, hits, cap, 0};
-    for (size_t k = 0; k < n_pixels && sink.n < cap; ++k)
-        render_pixel_sum(sc, use_bvh != 0, *cam, bg, width, height, sample_begin, sample_end, max_depth, seed,
-                         pixels[k], &sink);
-    return (int64_t)sink.n;
+    if (n_pixels < 512) {
+        TraceSink sink{rays, hits, cap, 0};
+        for (size_t k = 0; k < n_pixels && sink.n < cap; ++k)
+            render_pixel_sum(sc, use_bvh != 0, *cam, bg, width, height, sample_begin, sample_end, max_depth, seed,
+                             pixels[k], &sink);
+        return (int64_t)sink.n;
+    }
+    // Many pixels: blocks of pixels on all cores, each into a buffer of its own, put together in
+    // pixel order afterwards -- the same sequence of rays the serial loop records.
+    const size_t BLOCK_PIXELS = 64;
+    const size_t n_blocks = (n_pixels + BLOCK_PIXELS - 1) / BLOCK_PIXELS;
+    const size_t worst = BLOCK_PIXELS * (size_t)(sample_end - sample_begin) * max_depth;
+    std::vector<std::vector<mirt_ray>> block_rays(n_blocks);
+    std::vector<std::vector<mirt_hit>> block_hits(n_blocks);
+#pragma omp parallel
+    {
+        std::vector<mirt_ray> local_rays(worst);
+        std::vector<mirt_hit> local_hits(worst);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)n_blocks; ++b) {
+            TraceSink sink{local_rays.data(), local_hits.data(), worst, 0};
+            const size_t k_end = std::min(n_pixels, (size_t)(b + 1) * BLOCK_PIXELS);
+            for (size_t k = (size_t)b * BLOCK_PIXELS; k < k_end; ++k)
+                render_pixel_sum(sc, use_bvh != 0, *cam, bg, width, height, sample_begin, sample_end, max_depth, seed,
+                                 pixels[k], &sink);
+            block_rays[b].assign(local_rays.begin(), local_rays.begin() + sink.n);
+            block_hits[b].assign(local_hits.begin(), local_hits.begin() + sink.n);
+        }
+    }
+    size_t n = 0;
+    for (size_t b = 0; b < n_blocks && n < cap; ++b) {
+        const size_t take = std::min(block_rays[b].size(), cap - n);
+        std::memcpy(rays + n, block_rays[b].data(), take * sizeof(mirt_ray));
+        std::memcpy(hits + n, block_hits[b].data(), take * sizeof(mirt_hit));
+        n += take;
+    }
+    return (int64_t)n;
 }
 
 }  // extern "C"

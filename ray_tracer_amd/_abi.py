@@ -164,6 +164,7 @@ MIRT_SYMBOLS = {
     "mirt_device_count": (C.c_int, []),
     "mirt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "mirt_scene_destroy": (None, [C.c_void_p]),
+    "mirt_scene_trim": (C.c_int, [C.c_void_p]),
     "mirt_intersect": (
         C.c_int,
         [C.c_void_p, C.POINTER(Ray), C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(Hit)],

@@ -130,6 +130,10 @@ class Scene:
     def handle(self):
         return self._handle
 
+    def trim(self):
+        """Frees the per-pass buffers render calls keep with the scene (mirt_scene_trim)."""
+        _check(self._lib.mirt_scene_trim(self._handle))
+
     def close(self):
         if self._handle:
             self._lib.mirt_scene_destroy(self._handle)

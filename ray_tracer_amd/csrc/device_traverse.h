@@ -201,8 +201,10 @@ __device__ __forceinline__ void slab_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32x2 fy
 
 // A value of f32 not below x * (1 + 1e-6) for x >= 0 (not above, for x < 0), and the mirror
 // image: the culling range (t_lo, t_hi] must contain every t the f64 tests can accept.
-__device__ __forceinline__ float f32_not_below(double x) { return (float)(x + fabs(x) * 2.0e-6); }
-__device__ __forceinline__ float f32_not_above(double x) { return (float)(x - fabs(x) * 2.0e-6); }
+// An infinite x is returned as it is (inf - inf * 2e-6 would be a NaN: a range end that the min / max
+// of the culling tests would silently drop).
+__device__ __forceinline__ float f32_not_below(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x + fabs(x) * 2.0e-6); }
+__device__ __forceinline__ float f32_not_above(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x - fabs(x) * 2.0e-6); }
 
 // The reference's slab test (aabb.rs:24-51) on every gate of shape `prim`.  Rarely needed: a
 // call, so that its registers are not the kernels'.

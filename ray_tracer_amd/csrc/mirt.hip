@@ -264,6 +264,24 @@ static int validate_desc(const mirt_scene_desc* d) {
         }
         for (uint32_t i = 0; i + 1 < d->n_nodes; ++i)
             if (!member_used[i]) return fail(MIRT_ERR_INVALID_ARGUMENT, "BVH member %u is not reachable from the root", i);
+        // Leaves from left to right must be shapes 0, 1, 2, ...: the reference's build leaves them so
+        // (bvh.rs:24-26,179-236), and "equal t: the right subtree wins" (bvh.rs:70-74) is "the larger shape
+        // index wins" only then -- the fast traversal breaks ties by index.
+        std::vector<uint32_t> todo;
+        todo.push_back(d->n_nodes - 1);
+        uint32_t next_shape = 0;
+        while (!todo.empty()) {
+            const mirt_bvh_member& m = d->nodes[todo.back()];
+            todo.pop_back();
+            if (m.is_leaf) {
+                if (m.shape != next_shape)
+                    return fail(MIRT_ERR_INVALID_ARGUMENT, "BVH leaves must hold shapes 0, 1, 2, ... from left to right: found shape %u where %u belongs", m.shape, next_shape);
+                ++next_shape;
+            } else {
+                todo.push_back(m.right);
+                todo.push_back(m.left);
+            }
+        }
     }
     return MIRT_OK;
 }
@@ -433,6 +451,23 @@ void mirt_scene_destroy(mirt_scene* scene) {
     if (scene->ws_ptr) (void)hipFree(scene->ws_ptr);
     if (prev >= 0 && prev != scene->device) (void)hipSetDevice(prev);
     delete scene;
+}
+
+int mirt_scene_trim(mirt_scene* scene) {
+    if (!scene) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene is null");
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(scene->ws_mutex);
+        drop = scene->ws_ptr;
+        scene->ws_ptr = nullptr;
+        scene->ws_bytes = 0;
+    }
+    if (!drop) return MIRT_OK;
+    DeviceGuard guard;
+    int rc = guard.enter(scene->device);
+    if (rc != MIRT_OK) return rc;
+    HIP_TRY(hipFree(drop));
+    return MIRT_OK;
 }
 
 // -------------------------------------------------------------- intersect
@@ -635,6 +670,7 @@ int mirt_camera_rays(const mirt_camera* camera, uint32_t width, uint32_t height,
                      uint32_t pixel_end, uint32_t sample, uint64_t seed, int device, mirt_ray* rays) {
     if (!camera || !rays) return fail(MIRT_ERR_INVALID_ARGUMENT, "camera or rays is null");
     if (width == 0 || height == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image");
+    if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^31 pixels");
     if (pixel_end == 0) pixel_end = width * height;
     if (pixel_begin >= pixel_end || pixel_end > width * height) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad pixel range");
     if (mirt_device_count() == 0) return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible");
@@ -1105,6 +1141,7 @@ int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, u
                        uint8_t* out_rgb) {
     if (!d_accum || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
     if (width == 0 || height == 0 || spp == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image or spp = 0");
+    if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^31 pixels");
     if (pixel_end == 0) pixel_end = width * height;
     if (pixel_begin >= pixel_end || pixel_end > width * height) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad pixel range");
     if (tile_count > 1 && (tile_size == 0 || tile_index >= tile_count)) return fail(MIRT_ERR_INVALID_ARGUMENT, "bad tile split");

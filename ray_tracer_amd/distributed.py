@@ -25,8 +25,11 @@ def rows_of(rank, world_size, height):
 
 
 def sample_range(spp, rank, world_size):
-    """This rank's [begin, end) of the spp samples; the shares differ by at most one."""
-    return (rank * spp // world_size, (rank + 1) * spp // world_size)
+    """This rank's [begin, end) of the spp samples; the shares differ by at most one.  None when the
+    share is empty (fewer samples than ranks): such a rank renders nothing -- passing (0, 0) on would
+    mean "all samples" to mirt_render_accumulate -- and still takes part in the reduce with zeros."""
+    lo, hi = rank * spp // world_size, (rank + 1) * spp // world_size
+    return (lo, hi) if hi > lo else None
 
 
 def gather_rows(out, rank, world_size, group=None, dst=0):

@@ -79,6 +79,10 @@ def test_sample_shares_cover_the_range_exactly():
     for spp in (1, 7, 500):
         for n in (1, 2, 3, 8):
             shares = [distributed.sample_range(spp, r, n) for r in range(n)]
+            if spp < n:  # fewer samples than ranks: empty shares are None, never (0, 0) = "all samples"
+                assert sum(s is None for s in shares) == n - spp
+                assert sorted(s for s in shares if s is not None) == [(k, k + 1) for k in range(spp)]
+                continue
             assert shares[0][0] == 0 and shares[-1][1] == spp
             assert all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
             sizes = [b - a for a, b in shares]

@@ -304,3 +304,22 @@ def test_resolve_is_mean_sqrt_scale_and_saturating_cast():
     assert out.tolist() == [[0, 255, 255], [127, 255, 0], [0, 255, 255]]
     out = oracle_lib.resolve(sums * 4, 4)
     assert out.tolist() == [[0, 255, 255], [127, 255, 0], [0, 255, 255]]
+
+
+def test_parallel_trace_and_intersect_equal_the_serial_ones(oracle):
+    """oracle_trace_rays on many pixels and oracle_intersect on many rays use all cores; what they
+    return is the serial loops' output, in the same order."""
+    from ray_tracer_amd import configs
+
+    cfg = configs.C1
+    world = cfg.world()
+    w, h = 96, 54
+    cam = cfg.camera(w, h)
+    pixels = np.arange(w * h, dtype=np.uint32)
+    rays, hits = oracle.trace_rays(world.desc, cam, cfg.background, w, h, pixels, (0, 2))
+    parts = [oracle.trace_rays(world.desc, cam, cfg.background, w, h, pixels[k:k + 500], (0, 2)) for k in range(0, w * h, 500)]
+    assert np.array_equal(np.concatenate([p[0] for p in parts]).view(np.uint8), rays.view(np.uint8))
+    assert np.array_equal(np.concatenate([p[1] for p in parts]).view(np.uint8), hits.view(np.uint8))
+    again, _ = oracle.intersect(world.desc, rays)  # >= 4096 rays: parallel
+    small = np.concatenate([oracle.intersect(world.desc, rays[k:k + 1000])[0] for k in range(0, rays.shape[0], 1000)])
+    assert np.array_equal(again.view(np.uint8), hits.view(np.uint8)) and np.array_equal(small.view(np.uint8), hits.view(np.uint8))
