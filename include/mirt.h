@@ -309,6 +309,17 @@ int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera,
                            uint32_t spp, uint32_t max_depth, uint64_t seed,
                            const mirt_render_opts* opts, double* d_accum, mirt_stats* stats);
 
+/* An accumulation image for mirt_render_accumulate / mirt_resolve on `device` (-1 = current) for
+ * hosts that do not link the HIP runtime themselves (the reference's host is Rust): allocate (zeroed),
+ * free, copy to and from HOST memory (width*height*3 doubles, pixel-major RGB).  With these a host
+ * renders a frame in instalments -- samples [a, b) now, [b, c) later, even in another process after
+ * writing the doubles to a file -- and gets the sums of the one-call render bit for bit: samples are
+ * added to a pixel in sample order whatever the instalments (renderer.rs:77-84). */
+int mirt_accum_alloc(uint32_t width, uint32_t height, int device, double** d_accum);
+void mirt_accum_free(double* d_accum, int device);
+int mirt_accum_read(const double* d_accum, uint32_t width, uint32_t height, int device, double* host);
+int mirt_accum_write(double* d_accum, uint32_t width, uint32_t height, int device, const double* host);
+
 /* mirt_render_accumulate for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arguments, same sums in d_accum bit for bit; it calls no hipMalloc / hipFree: the radiance

@@ -57,6 +57,10 @@ int mirt_host_perlin_new(uint64_t seed, mirt_perlin* out);
 /* ppm::create (src/ppm.rs:6-27): ASCII P3. */
 int mirt_host_ppm_create(const char* output_path, uint32_t image_x, uint32_t image_y, const uint8_t* bytes);
 
+/* The same pixels as binary PPM: "P6\n<w> <h>\n255\n" then 3 bytes per pixel.  Not in the reference
+ * (src/ppm.rs writes P3 only, one formatted line per pixel: 8.3 M lines for a 3840x2160 frame). */
+int mirt_host_ppm_create_binary(const char* output_path, uint32_t image_x, uint32_t image_y, const uint8_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,6 +239,10 @@ MIRT_SYMBOLS = {
             C.POINTER(Stats),
         ],
     ),
+    "mirt_accum_alloc": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "mirt_accum_free": (None, [C.c_void_p, C.c_int]),
+    "mirt_accum_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
+    "mirt_accum_write": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     "mirt_resolve": (
         C.c_int,
         [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint8)],
@@ -287,6 +291,7 @@ HOST_SYMBOLS = {
     ),
     "mirt_host_perlin_new": (C.c_int, [C.c_uint64, C.POINTER(Perlin)]),
     "mirt_host_ppm_create": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]),
+    "mirt_host_ppm_create_binary": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]),
 }
 
 

@@ -1130,6 +1130,62 @@ int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera, c
     return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats);
 }
 
+static int accum_values(uint32_t width, uint32_t height, size_t* n) {
+    if (width == 0 || height == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image");
+    if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^31 pixels");
+    *n = (size_t)width * height * 3;
+    return MIRT_OK;
+}
+
+int mirt_accum_alloc(uint32_t width, uint32_t height, int device, double** d_accum) {
+    if (!d_accum) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
+    *d_accum = nullptr;
+    size_t n = 0;
+    int rc = accum_values(width, height, &n);
+    if (rc != MIRT_OK) return rc;
+    if (mirt_device_count() == 0) return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible");
+    DeviceGuard guard;
+    if ((rc = guard.enter(device)) != MIRT_OK) return rc;
+    double* p = nullptr;
+    HIP_TRY(hipMalloc((void**)&p, n * sizeof(double)));
+    hipError_t e = hipMemset(p, 0, n * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(MIRT_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    *d_accum = p;
+    return MIRT_OK;
+}
+
+void mirt_accum_free(double* d_accum, int device) {
+    if (!d_accum) return;
+    DeviceGuard guard;
+    if (guard.enter(device) != MIRT_OK) return;
+    (void)hipFree(d_accum);
+}
+
+int mirt_accum_read(const double* d_accum, uint32_t width, uint32_t height, int device, double* host) {
+    if (!d_accum || !host) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
+    size_t n = 0;
+    int rc = accum_values(width, height, &n);
+    if (rc != MIRT_OK) return rc;
+    DeviceGuard guard;
+    if ((rc = guard.enter(device)) != MIRT_OK) return rc;
+    HIP_TRY(hipMemcpy(host, d_accum, n * sizeof(double), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+int mirt_accum_write(double* d_accum, uint32_t width, uint32_t height, int device, const double* host) {
+    if (!d_accum || !host) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
+    size_t n = 0;
+    int rc = accum_values(width, height, &n);
+    if (rc != MIRT_OK) return rc;
+    DeviceGuard guard;
+    if ((rc = guard.enter(device)) != MIRT_OK) return rc;
+    HIP_TRY(hipMemcpy(d_accum, host, n * sizeof(double), hipMemcpyHostToDevice));
+    return MIRT_OK;
+}
+
 int mirt_render_accumulate_static(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
                                   uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
                                   const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {

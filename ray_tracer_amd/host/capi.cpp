@@ -105,4 +105,10 @@ int mirt_host_ppm_create(const char* output_path, uint32_t image_x, uint32_t ima
     return rt::ppm_create(output_path, image_x, image_y, v) ? MIRT_OK : host_fail("cannot write ppm");
 }
 
+int mirt_host_ppm_create_binary(const char* output_path, uint32_t image_x, uint32_t image_y, const uint8_t* bytes) {
+    if (!output_path || !bytes) return host_fail("null argument");
+    std::vector<uint8_t> v(bytes, bytes + (size_t)image_x * image_y * 3);
+    return rt::ppm_create_binary(output_path, image_x, image_y, v) ? MIRT_OK : host_fail("cannot write ppm");
+}
+
 }  // extern "C"

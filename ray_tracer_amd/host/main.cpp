@@ -7,19 +7,44 @@
 //    seeds from entropy, main.rs:64, renderer.rs:30; without the variable so does this);
 //  * TRACER_BACKGROUND="r,g,b" overrides the hard-coded black background
 //    (main.rs:80-81 keeps the sky colour only as a comment).
+//  * long renders can be cut into instalments and survive the end of a process (the reference renders a
+//    frame in one call or not at all): --checkpoint FILE (or TRACER_CHECKPOINT) keeps the f64 accumulation
+//    image in FILE, written after every --checkpoint-every K samples per pixel (TRACER_CHECKPOINT_EVERY;
+//    default: once, at the end of the run), and a run that finds FILE goes on where it stops, with the
+//    seed it holds; --stop-after S (TRACER_STOP_AFTER) ends this run once S samples per pixel are done;
+//  * --format p6 (TRACER_OUTPUT_FORMAT, or file_type = "p6" in [output]) writes binary PPM instead of the
+//    reference's ASCII P3 (ppm.rs:6-27), which stays the default.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
+#include <stdexcept>
 #include <string>
 
 #include "config.hpp"
 #include "scene.hpp"
 
-int main() {
+namespace {
+// --name VALUE on the command line, else the environment variable, else ""
+std::string option(int argc, char** argv, const char* flag, const char* env) {
+    for (int i = 1; i + 1 < argc; ++i)
+        if (std::strcmp(argv[i], flag) == 0) return argv[i + 1];
+    const char* e = std::getenv(env);
+    return e ? e : "";
+}
+}  // namespace
+
+int main(int argc, char** argv) {
     using clock = std::chrono::steady_clock;
     auto elapsed = [](clock::time_point t0) { return std::chrono::duration<double>(clock::now() - t0).count(); };
     try {
+        rt::Checkpointing ckpt;
+        ckpt.path = option(argc, argv, "--checkpoint", "TRACER_CHECKPOINT");
+        ckpt.every = (size_t)std::strtoull(option(argc, argv, "--checkpoint-every", "TRACER_CHECKPOINT_EVERY").c_str(), nullptr, 0);
+        ckpt.stop_after = (size_t)std::strtoull(option(argc, argv, "--stop-after", "TRACER_STOP_AFTER").c_str(), nullptr, 0);
+        std::string format = option(argc, argv, "--format", "TRACER_OUTPUT_FORMAT");
+
         const char* env_path = std::getenv("TRACER_CONFIG_PATH");
         const std::string config_path = env_path ? env_path : "./resources/tracer.toml";
         const rt::TracerConfig cfg = rt::read_tracer_config(config_path);
@@ -33,9 +58,16 @@ int main() {
             cfg.camera.look_from, cfg.camera.look_at, v_up, cfg.camera.fov, (double)screen_width / (double)screen_height,
             cfg.camera.aperture, focus_distance, cfg.camera.time_start, cfg.camera.time_end);
 
-        uint64_t seed;
+        if (format.empty()) format = cfg.output.file_type;
+        const bool binary = format == "p6" || format == "P6";
+        if (!binary && !format.empty() && format != "p3" && format != "P3" && format != "ppm")
+            throw std::runtime_error("unknown output format " + format + " (p3, p6)");
+
+        uint64_t seed, resumed_seed = 0;
         if (const char* s = std::getenv("TRACER_SEED")) {
             seed = std::strtoull(s, nullptr, 0);
+        } else if (!ckpt.path.empty() && rt::checkpoint_seed(ckpt.path, &resumed_seed)) {
+            seed = resumed_seed ^ 0x5EED0002ull;  // the run that wrote the checkpoint drew it
         } else {
             std::random_device rd;
             seed = ((uint64_t)rd() << 32) ^ rd();
@@ -55,9 +87,18 @@ int main() {
             if (std::sscanf(bg, "%lf,%lf,%lf", &r, &g, &b) == 3) background = rt::Vec3(r, g, b);
         }
         mirt_stats stats{};
-        const std::vector<uint8_t> buffer =
-            rt::render_world(background, world, camera, screen_width, screen_height, cfg.renderer.antialias_iterations,
-                             cfg.renderer.render_parallel, cfg.renderer.use_bounding_volume, seed ^ 0x5EED0002ull, &stats);
+        std::vector<uint8_t> buffer;
+        if (ckpt.path.empty() && ckpt.every == 0 && ckpt.stop_after == 0) {
+            buffer = rt::render_world(background, world, camera, screen_width, screen_height, cfg.renderer.antialias_iterations,
+                                      cfg.renderer.render_parallel, cfg.renderer.use_bounding_volume, seed ^ 0x5EED0002ull, &stats);
+        } else {
+            size_t done = 0;
+            bool finished = false;
+            buffer = rt::render_world_resumable(background, world, camera, screen_width, screen_height, cfg.renderer.antialias_iterations,
+                                                cfg.renderer.use_bounding_volume, seed ^ 0x5EED0002ull, ckpt, &stats, &done, &finished);
+            std::printf("  %zu of %zu samples per pixel done%s\n", done, (size_t)cfg.renderer.antialias_iterations,
+                        finished ? "" : " (unfinished: the image is the mean of these; run again to go on)");
+        }
         const double tracing = elapsed(tracing_start);
         std::printf("End tracing-- took %.2fs\n", tracing);
         std::printf("  %.3f Msamples/s, %.3f Mrays/s (%llu samples, %llu ray segments)\n", stats.samples / tracing / 1e6,
@@ -65,7 +106,8 @@ int main() {
 
         auto ppm_start = clock::now();
         std::printf("Start ppm creation\n");
-        if (!rt::ppm_create(cfg.output.output_path, screen_width, screen_height, buffer)) {
+        if (!(binary ? rt::ppm_create_binary(cfg.output.output_path, screen_width, screen_height, buffer)
+                     : rt::ppm_create(cfg.output.output_path, screen_width, screen_height, buffer))) {
             std::fprintf(stderr, "cannot write %s\n", cfg.output.output_path.c_str());
             return 1;
         }

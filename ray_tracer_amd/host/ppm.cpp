@@ -27,4 +27,16 @@ bool ppm_create(const std::string& output_path, size_t image_x, size_t image_y, 
     return ok;
 }
 
+// Binary PPM (P6) of the same pixels: the header with P6, then the bytes as they are.
+bool ppm_create_binary(const std::string& output_path, size_t image_x, size_t image_y, const std::vector<uint8_t>& bytes) {
+    std::FILE* f = std::fopen(output_path.c_str(), "wb");
+    if (!f) return false;
+    const std::string header = "P6\n" + std::to_string(image_x) + " " + std::to_string(image_y) + "\n255\n";
+    const size_t n = bytes.size() / 3 * 3;
+    bool ok = std::fwrite(header.data(), 1, header.size(), f) == header.size();
+    ok = ok && std::fwrite(bytes.data(), 1, n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok;
+}
+
 }  // namespace rt

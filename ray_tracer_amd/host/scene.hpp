@@ -174,6 +174,25 @@ std::vector<uint8_t> render_world(const Vec3& background, const BoundingVolumeHi
 
 // src/ppm.rs:6-27
 bool ppm_create(const std::string& output_path, size_t image_x, size_t image_y, const std::vector<uint8_t>& bytes);
+bool ppm_create_binary(const std::string& output_path, size_t image_x, size_t image_y, const std::vector<uint8_t>& bytes);
 bool read_ppm_p6(const std::string& path, Image* out);
+
+// render_world in instalments with a checkpoint file: after every `every` samples per pixel the f64
+// accumulation image is written to `path` (to a temporary name first, then renamed); a run that finds
+// `path` continues after the samples it holds.  `stop_after` > 0 ends this run once that many samples
+// per pixel are in the checkpoint (the frame is then unfinished: the returned bytes are the mean of
+// the samples so far and *finished = false).  The sums, and so the bytes of the finished frame, are
+// those of one uninterrupted call bit for bit.  stats adds up over the instalments of THIS run.
+struct Checkpointing {
+    std::string path;        // empty: no checkpoint file
+    size_t every = 0;        // samples per pixel per instalment; 0 = all that are left
+    size_t stop_after = 0;   // 0 = run to the end
+};
+// The sampler seed a checkpoint file was written with (false: no such file, or not a checkpoint).
+bool checkpoint_seed(const std::string& path, uint64_t* render_seed);
+std::vector<uint8_t> render_world_resumable(const Vec3& background, const BoundingVolumeHierarchy& world, const Camera& camera,
+                                            size_t screen_width, size_t screen_height, size_t antialias_iterations,
+                                            bool use_bounding_volume, uint64_t seed, const Checkpointing& ckpt,
+                                            mirt_stats* stats, size_t* samples_done, bool* finished);
 
 }  // namespace rt

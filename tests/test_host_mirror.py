@@ -130,6 +130,13 @@ def test_ppm_create_writes_the_reference_format(tmp_path):
     assert abi.libhost().mirt_host_ppm_create(b"/nonexistent-dir/x.ppm", 2, 3, px.ctypes.data_as(C.POINTER(C.c_uint8))) != 0
 
 
+def test_binary_ppm_holds_the_same_pixels(tmp_path):
+    px = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(3, 2, 3) * 13
+    path = tmp_path / "out.ppm"
+    assert abi.libhost().mirt_host_ppm_create_binary(str(path).encode(), 2, 3, px.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert path.read_bytes() == b"P6\n2 3\n255\n" + px.tobytes()
+
+
 # ------------------------------------------------------------------ the command line
 GOOD_TOML = """
 [output]
