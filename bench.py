@@ -58,6 +58,9 @@ def parse_args():
                          "bounce below bounce N, -1 = launches per bounce throughout, -2 = probe")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work to spend on the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak (default) = the same frame at N times the samples per pixel, so every GPU renders as many "
+                         "samples as the one GPU of N = 1; strong = the configuration's own samples per pixel shared out")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collectives between the ranks: nccl (RCCL over xGMI, one GPU per rank) or gloo (host memory; ranks "
                          "may then share a GPU: rank r uses device r mod the number of devices -- a rehearsal on a smaller box)")
@@ -150,6 +153,9 @@ def main():
     cfg = configs.ALL[args.config]
     if args.spp or args.width or args.height:
         cfg = cfg.scaled(args.width or cfg.width, args.height or cfg.height, args.spp or cfg.spp)
+    spp_one_gpu = cfg.spp
+    if n_ranks > 1 and args.scaling == "weak":
+        cfg = cfg.scaled(cfg.width, cfg.height, cfg.spp * n_ranks)
     W, H, spp = cfg.width, cfg.height, cfg.spp
     world = cfg.world()
     cam = cfg.camera()
@@ -238,13 +244,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if n_ranks > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (seeded scene generator, world seed 0x5EED0001, render seed 0x5EED0002)",
             "config": {
                 "workload": cfg.name,
-                "width": W, "height": H, "spp": spp, "max_depth": api.MAX_DEPTH,
+                "width": W, "height": H, "spp": spp, "spp_at_one_gpu": spp_one_gpu, "max_depth": api.MAX_DEPTH,
                 "shapes": world.n_shapes, "bvh_members": world.n_nodes,
                 "split": args.split if n_ranks > 1 else "none",
                 "ranks": ("one process, one host thread per device (mirt_render_multi)" if args.single_process and n_ranks > 1
