@@ -6,10 +6,15 @@
 One step = one full render of the configuration (default C2: the RTIOW random-sphere
 scene at 1200x800, 500 spp, depth 50) through the C ABI (mirt_render), scene already
 resident in HBM.  Metric: Msamples/s = width * height * spp * steps / seconds, whole
-job.  With N > 1 (one process per GPU, launched by torch.distributed.run) the frame is
-split by interleaved rows across ranks (no data-path collective; rank 0 gathers the
-rendered rows), or with --split sample every rank renders all pixels for spp/N of the
-samples and the f64 accumulation images are summed with one RCCL reduce.
+job.  With N > 1 -- one process per GPU: under torch.distributed.run as the driver starts
+it, or from a plain shell, in which case this script starts the N ranks itself -- the
+frame is split by interleaved rows across ranks (no data-path collective; rank 0 gathers
+the rendered rows), or with --split sample every rank renders all pixels for its share of
+the samples and the f64 accumulation images are summed with one RCCL reduce.  Scaling is
+weak by default: the same frame at N times the samples per pixel, so that every GPU
+renders as many samples as the one GPU of N = 1 does (--scaling strong shares out the
+configuration's own 500).  --single-process renders on the N devices from one process
+through mirt_render_multi instead; --backend gloo lets ranks share a GPU (a rehearsal).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with
 the bytes a queue-per-bounce pipeline moves for the same work (272 per path segment + 24
@@ -159,7 +164,9 @@ def main():
     W, H, spp = cfg.width, cfg.height, cfg.spp
     world = cfg.world()
     cam = cfg.camera()
+    t_upload = time.perf_counter()
     scene = api.Scene(world)  # scene resident in HBM before the timed region
+    scene_upload_ms = (time.perf_counter() - t_upload) * 1e3  # culling-tree build on the host + copies; outside `value`
     rank_scenes = [scene]
     if args.single_process and args.gpus > 1:
         # one scene per rank, on device r (on a box with fewer devices the ranks share them)
@@ -261,6 +268,7 @@ def main():
             },
             "handover": {"bounce": int(step_stats[-1]["handover_bounce"]),
                          "path_kernel_segments_frac": tot["segments_paths"] / max(1.0, tot["segments"])},
+            "scene_upload_ms": scene_upload_ms,
             "mrays_per_s": tot["segments"] / elapsed / 1e6,
             "segments_per_sample": tot["segments"] / samples,
         }

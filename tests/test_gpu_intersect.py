@@ -252,3 +252,65 @@ def test_ties_go_to_the_shape_the_reference_picks(oracle):
         _compare(scene.hit(rays, use_bvh=False), first, "ties, list")
     finally:
         scene.close()
+
+
+def test_cubes_of_every_description(oracle):
+    """Cubes with unordered corners (some faces can then never be hit, hittable.rs:189-197), flat cubes,
+    cubes touching along faces and edges, huge and tiny ones side by side; rays from outside, from inside,
+    from points on the faces, along edges and through corners.  The fast traversal names the faces
+    that can matter from f32 bounds before it tests them exactly: no answer may change."""
+    import scene_util as su
+
+    rng = np.random.default_rng(21)
+    shapes = []
+    for k in range(90):
+        c = np.round(rng.uniform(-12.0, 12.0, 3) * 2.0) / 2.0
+        size = np.round(rng.uniform(0.5, 4.0, 3) * 2.0) / 2.0
+        p0, p1 = c.copy(), c + size
+        if k % 6 == 1:   # unordered on one or two axes
+            a = rng.integers(0, 3)
+            p0[a], p1[a] = p1[a], p0[a]
+            if k % 12 == 1:
+                b = (a + 1) % 3
+                p0[b], p1[b] = p1[b], p0[b]
+        elif k % 6 == 2:  # flat
+            p1[rng.integers(0, 3)] = p0[rng.integers(0, 3)]
+        elif k % 6 == 3:  # tiny next to everything else
+            p1 = p0 + 1.0e-6
+        elif k % 6 == 4:  # large
+            p1 = p0 + 40.0
+        shapes.append(su.shape(abi.SHAPE_CUBE, 0, *p0, *p1))
+        if k % 5 == 0:    # a neighbour sharing the face x = p1.x
+            shapes.append(su.shape(abi.SHAPE_CUBE, 0, p1[0], p0[1], p0[2], p1[0] + 1.5, p1[1], p1[2]))
+    built = su.Built(shapes, seed=9)
+    n = 400_000
+    rays = np.zeros(n, dtype=api.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-20.0, 20.0, (n, 3))
+    target = rng.uniform(-14.0, 18.0, (n, 3))
+    rays["direction"] = (target - rays["origin"]) * rng.uniform(0.1, 4.0, (n, 1))
+    q = n // 8
+    # onto the half-unit lattice the corners live on: edges, corners, coplanar faces
+    rays["origin"][:q] = np.round(rays["origin"][:q] * 2.0) / 2.0
+    rays["direction"][:q] = np.round(target[:q] * 2.0) / 2.0 - rays["origin"][:q]
+    # diagonal directions through lattice points
+    rays["direction"][q:2 * q] = rng.choice([-1.0, 1.0, 2.0, -0.5], (q, 3))
+    rays["origin"][q:2 * q] = np.round(rays["origin"][q:2 * q] * 2.0) / 2.0
+    # starting on a face of some cube (what a scattered ray does)
+    for i in range(2 * q, 3 * q):
+        s = built.shapes[i % built.desc.n_shapes]
+        lo, hi = np.array(s.f[0:3]), np.array(s.f[3:6])
+        o = lo + (hi - lo) * rng.uniform(0.0, 1.0, 3)
+        a = rng.integers(0, 3)
+        o[a] = (lo, hi)[rng.integers(0, 2)][a]
+        rays["origin"][i] = o
+    ref, _ = oracle.intersect(built.desc, rays)
+    assert np.count_nonzero(ref["prim"] >= 0) > n // 4 and len(np.unique(ref["side"])) == 6
+    scene = api.Scene(built.desc)
+    try:
+        _compare(scene.hit(rays), ref, "cubes, fast")
+        _compare(scene.hit(rays, traversal=abi.TRAVERSE_REFERENCE), ref, "cubes, reference-order")
+        for t_min, t_max in ((0.5, 2.0), (-3.0, 0.75)):
+            ref_r, _ = oracle.intersect(built.desc, rays, t_min=t_min, t_max=t_max)
+            _compare(scene.hit(rays, t_min=t_min, t_max=t_max), ref_r, f"cubes, range ({t_min}, {t_max})")
+    finally:
+        scene.close()
