@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -34,6 +35,21 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     tl_error = buf;
     return code;
+}
+
+// Nothing may propagate across the C boundary: an entry point whose body allocates host memory (vectors,
+// threads) runs it through this.
+template <class F>
+int no_throw(F body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(MIRT_ERR_OUT_OF_MEMORY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(MIRT_ERR_HIP, "unexpected failure: %s", e.what());
+    } catch (...) {
+        return fail(MIRT_ERR_HIP, "unexpected failure");
+    }
 }
 
 #define HIP_TRY(expr)                                                                            \
@@ -286,7 +302,7 @@ static int validate_desc(const mirt_scene_desc* d) {
     return MIRT_OK;
 }
 
-int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out) {
+static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene** out) {
     if (!out) return fail(MIRT_ERR_INVALID_ARGUMENT, "out is null");
     *out = nullptr;
     int rc = validate_desc(desc);
@@ -353,7 +369,8 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     const uint32_t root_ref = tree.root_ref, height = tree.height;
 
     // ---- upload
-    auto* sc = new (std::nothrow) mirt_scene();
+    std::unique_ptr<mirt_scene> owner(new (std::nothrow) mirt_scene());
+    mirt_scene* sc = owner.get();
     if (!sc) return fail(MIRT_ERR_OUT_OF_MEMORY, "out of host memory");
     sc->device = dev;
     sc->has_bvh = desc->nodes != nullptr;
@@ -378,7 +395,6 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess) {                                                                           \
-            delete sc;                                                                                    \
             return fail(e_ == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_HIP, "%s failed: %s", \
                         #expr, hipGetErrorString(e_));                                                    \
         }                                                                                                 \
@@ -438,8 +454,12 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
     if (sc->cu_count <= 0) sc->cu_count = 256;
     sc->allocations = arena.ptrs;
     arena.release();
-    *out = sc;
+    *out = owner.release();
     return MIRT_OK;
+}
+
+int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out) {
+    return no_throw([&] { return scene_create_body(desc, device, out); });
 }
 
 void mirt_scene_destroy(mirt_scene* scene) {
@@ -1192,9 +1212,9 @@ int mirt_render_accumulate_static(const mirt_scene* scene, const mirt_camera* ca
     return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats, true);
 }
 
-int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
-                       uint32_t pixel_end, uint32_t tile_size, uint32_t tile_count, uint32_t tile_index, int device,
-                       uint8_t* out_rgb) {
+static int resolve_tiles_body(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
+                              uint32_t pixel_end, uint32_t tile_size, uint32_t tile_count, uint32_t tile_index, int device,
+                              uint8_t* out_rgb) {
     if (!d_accum || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
     if (width == 0 || height == 0 || spp == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image or spp = 0");
     if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^31 pixels");
@@ -1230,6 +1250,12 @@ int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, u
         std::memcpy(out_rgb + (size_t)px.idx(k) * 3, compact.data() + (size_t)k * 3, (size_t)run * 3);
     }
     return MIRT_OK;
+}
+
+int mirt_resolve_tiles(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
+                       uint32_t pixel_end, uint32_t tile_size, uint32_t tile_count, uint32_t tile_index, int device,
+                       uint8_t* out_rgb) {
+    return no_throw([&] { return resolve_tiles_body(d_accum, width, height, spp, pixel_begin, pixel_end, tile_size, tile_count, tile_index, device, out_rgb); });
 }
 
 int mirt_resolve(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,

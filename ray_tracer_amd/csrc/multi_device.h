@@ -116,12 +116,19 @@ int run_ranks(uint32_t n, F fn) {
     std::vector<RankResult> results(n);
     std::vector<std::thread> threads;
     threads.reserve(n);
-    for (uint32_t r = 0; r < n; ++r)
-        threads.emplace_back([&, r] {
-            results[r].rc = fn(r);
-            if (results[r].rc != MIRT_OK) results[r].error = tl_error;
-        });
+    bool started_all = true;
+    for (uint32_t r = 0; r < n && started_all; ++r) {
+        try {
+            threads.emplace_back([&, r] {
+                results[r].rc = no_throw([&] { return fn(r); });
+                if (results[r].rc != MIRT_OK) results[r].error = tl_error;
+            });
+        } catch (...) {  // the system would not start another thread
+            started_all = false;
+        }
+    }
     for (auto& t : threads) t.join();
+    if (!started_all) return fail(MIRT_ERR_OUT_OF_MEMORY, "could not start a host thread per rank");
     for (uint32_t r = 0; r < n; ++r)
         if (results[r].rc != MIRT_OK) return fail(results[r].rc, "rank %u: %s", r, results[r].error.c_str());
     return MIRT_OK;
@@ -129,10 +136,10 @@ int run_ranks(uint32_t n, F fn) {
 
 }  // namespace
 
-extern "C" int mirt_render_multi(const mirt_scene* const* scenes, uint32_t n_scenes, const mirt_camera* camera,
-                                 const double background[3], uint32_t width, uint32_t height, uint32_t spp,
-                                 uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
-                                 const mirt_multi_opts* multi, uint8_t* out_rgb, mirt_stats* stats) {
+static int render_multi_body(const mirt_scene* const* scenes, uint32_t n_scenes, const mirt_camera* camera,
+                             const double background[3], uint32_t width, uint32_t height, uint32_t spp,
+                             uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
+                             const mirt_multi_opts* multi, uint8_t* out_rgb, mirt_stats* stats) {
     if (!scenes || n_scenes == 0 || !camera || !background || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
     if (n_scenes > MULTI_MAX_RANKS) return fail(MIRT_ERR_UNSUPPORTED, "more than %u scenes", MULTI_MAX_RANKS);
     for (uint32_t r = 0; r < n_scenes; ++r)
@@ -269,4 +276,11 @@ extern "C" int mirt_render_multi(const mirt_scene* const* scenes, uint32_t n_sce
             stats[r].ms_total = ms;
         }
     return MIRT_OK;
+}
+
+extern "C" int mirt_render_multi(const mirt_scene* const* scenes, uint32_t n_scenes, const mirt_camera* camera,
+                                 const double background[3], uint32_t width, uint32_t height, uint32_t spp,
+                                 uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
+                                 const mirt_multi_opts* multi, uint8_t* out_rgb, mirt_stats* stats) {
+    return no_throw([&] { return render_multi_body(scenes, n_scenes, camera, background, width, height, spp, max_depth, seed, opts, multi, out_rgb, stats); });
 }
