@@ -91,3 +91,33 @@ def test_sample_shares_cover_the_range_exactly():
         for n in (1, 2, 3, 8):
             rows = sorted(r for k in range(n) for r in distributed.rows_of(k, n, h))
             assert rows == list(range(h))
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_shell(monkeypatch):
+    """`python bench.py --gpus N` without torch.distributed.run around it: the script must start N fresh
+    processes itself (before it touches a GPU) with the arguments it was given, on the loopback address."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, *a, **kw):
+        seen["cmd"] = cmd
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as stop:
+        bench.main()
+    assert stop.value.code == 7  # the children's exit status is the script's
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2"]
