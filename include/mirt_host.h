@@ -28,7 +28,8 @@ const char* mirt_host_last_error(void);
  * benchmark configurations compose from the same constructors).
  * max_objects: WorldConfig::Dynamic.max_objects.  seed: seeds the stand-in for the
  * reference's entropy-seeded rng (main.rs:64).  earth_image (nullable): a decoded
- * RGB8 image for Texture::image; else earth_path (nullable; binary PPM) is read;
+ * RGB8 image for Texture::image; else earth_path (nullable; baseline JPEG or binary PPM;
+ * default ./resources/earthmap.jpg as world.rs:201) is read;
  * on failure the texture falls back to constant (0,1,1) like texture.rs:171-178. */
 int mirt_host_world_create(const char* scene_name, uint64_t max_objects, uint64_t seed, double time_initial,
                            double time_final, const mirt_image* earth_image, const char* earth_path,
@@ -56,6 +57,11 @@ int mirt_host_perlin_new(uint64_t seed, mirt_perlin* out);
 
 /* ppm::create (src/ppm.rs:6-27): ASCII P3. */
 int mirt_host_ppm_create(const char* output_path, uint32_t image_x, uint32_t image_y, const uint8_t* bytes);
+
+/* The file reading behind Texture::image (src/texture.rs:169-181; the reference uses the `image` crate):
+ * a baseline JPEG (what resources/earthmap.jpg is) or a binary PPM, to tightly packed RGB8, row 0 = top.
+ * With rgb = NULL only width and height are returned; otherwise capacity must be >= width*height*3. */
+int mirt_host_image_read(const char* path, uint32_t* width, uint32_t* height, uint8_t* rgb, size_t capacity);
 
 /* The same pixels as binary PPM: "P6\n<w> <h>\n255\n" then 3 bytes per pixel.  Not in the reference
  * (src/ppm.rs writes P3 only, one formatted line per pixel: 8.3 M lines for a 3840x2160 frame). */

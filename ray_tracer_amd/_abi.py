@@ -291,6 +291,7 @@ HOST_SYMBOLS = {
     ),
     "mirt_host_perlin_new": (C.c_int, [C.c_uint64, C.POINTER(Perlin)]),
     "mirt_host_ppm_create": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]),
+    "mirt_host_image_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_size_t]),
     "mirt_host_ppm_create_binary": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]),
 }
 

@@ -111,4 +111,22 @@ int mirt_host_ppm_create_binary(const char* output_path, uint32_t image_x, uint3
     return rt::ppm_create_binary(output_path, image_x, image_y, v) ? MIRT_OK : host_fail("cannot write ppm");
 }
 
+int mirt_host_image_read(const char* path, uint32_t* width, uint32_t* height, uint8_t* rgb, size_t capacity) {
+    if (!path || !width || !height) return host_fail("null argument");
+    try {
+        rt::Image img;
+        std::string why;
+        if (!rt::read_image(path, &img, &why)) return host_fail(std::string(path) + ": " + why);
+        *width = img.width;
+        *height = img.height;
+        if (rgb) {
+            if (capacity < img.rgb.size()) return host_fail("buffer too small for the image");
+            std::memcpy(rgb, img.rgb.data(), img.rgb.size());
+        }
+        return MIRT_OK;
+    } catch (const std::exception& e) {
+        return host_fail(e.what());
+    }
+}
+
 }  // extern "C"

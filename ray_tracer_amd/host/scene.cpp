@@ -78,11 +78,31 @@ bool read_ppm_p6(const std::string& path, Image* out) {
     return in.gcount() == (std::streamsize)out->rgb.size();
 }
 
+bool read_image(const std::string& path, Image* out, std::string* why) {
+    unsigned char magic[2] = {0, 0};
+    {
+        std::ifstream in(path, std::ios::binary);
+        if (!in || !in.read(reinterpret_cast<char*>(magic), 2)) {
+            if (why) *why = "cannot open the file";
+            return false;
+        }
+    }
+    if (magic[0] == 0xFF && magic[1] == 0xD8) return read_jpeg_baseline(path, out, why);
+    if (magic[0] == 'P' && magic[1] == '6') {
+        if (read_ppm_p6(path, out)) return true;
+        if (why) *why = "malformed binary PPM";
+        return false;
+    }
+    if (why) *why = "neither a JPEG nor a binary PPM (P6)";
+    return false;
+}
+
 Texture Texture::image(const std::string& filepath) {
     auto img = std::make_shared<Image>();
-    if (!read_ppm_p6(filepath, img.get())) {
+    std::string why;
+    if (!read_image(filepath, img.get(), &why)) {
         // texture.rs:173-177: log and fall back to the cyan error texture
-        std::fprintf(stderr, "Unable to load image \"%s\": not a readable binary PPM (P6)\n", filepath.c_str());
+        std::fprintf(stderr, "Unable to load image \"%s\": %s\n", filepath.c_str(), why.c_str());
         return constant(0.0, 1.0, 1.0);
     }
     return image(img);

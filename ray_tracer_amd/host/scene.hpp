@@ -138,7 +138,7 @@ enum class WorldKind { Basic, Dynamic, Checker, Perlin, Earth, SimpleLight, Corn
 struct WorldConfig {
     WorldKind scene = WorldKind::Basic;
     size_t max_objects = 10;                 // config.rs:199-201
-    std::string earth_path = "resources/earthmap.ppm";  // world.rs:201 names earthmap.jpg; same image, decoded
+    std::string earth_path = "./resources/earthmap.jpg";  // world.rs:201
     std::shared_ptr<Image> earth_image;      // already decoded image, takes precedence over earth_path
 };
 
@@ -176,6 +176,10 @@ std::vector<uint8_t> render_world(const Vec3& background, const BoundingVolumeHi
 bool ppm_create(const std::string& output_path, size_t image_x, size_t image_y, const std::vector<uint8_t>& bytes);
 bool ppm_create_binary(const std::string& output_path, size_t image_x, size_t image_y, const std::vector<uint8_t>& bytes);
 bool read_ppm_p6(const std::string& path, Image* out);
+// Baseline JPEG (what the reference's resources/earthmap.jpg is); *why says what was wrong with the file.
+bool read_jpeg_baseline(const std::string& path, Image* out, std::string* why);
+// Texture::image's file reading (texture.rs:169-181): a baseline JPEG or a binary PPM, told apart by their first bytes.
+bool read_image(const std::string& path, Image* out, std::string* why);
 
 // render_world in instalments with a checkpoint file: after every `every` samples per pixel the f64
 // accumulation image is written to `path` (to a temporary name first, then renamed); a run that finds

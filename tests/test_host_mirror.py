@@ -137,6 +137,69 @@ def test_binary_ppm_holds_the_same_pixels(tmp_path):
     assert path.read_bytes() == b"P6\n2 3\n255\n" + px.tobytes()
 
 
+def _read_image(path):
+    w, h = C.c_uint32(), C.c_uint32()
+    rc = abi.libhost().mirt_host_image_read(str(path).encode(), C.byref(w), C.byref(h), None, 0)
+    if rc != 0:
+        return None, abi.libhost().mirt_host_last_error().decode()
+    buf = np.zeros((h.value, w.value, 3), dtype=np.uint8)
+    assert abi.libhost().mirt_host_image_read(str(path).encode(), C.byref(w), C.byref(h), buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size) == 0
+    return buf, ""
+
+
+def test_the_reference_earth_texture_is_read_as_the_jpeg_it_is():
+    """texture.rs:169-181 opens ./resources/earthmap.jpg (world.rs:201) with the `image` crate; the host reads the
+    same file with its own baseline JPEG decoder.  Texel values are pinned by no test of the reference (decoders
+    differ by a level here and there in their inverse DCT): the check is against another decoder's output,
+    resources/earthmap.ppm (libjpeg through PIL, tools/make_earthmap.py)."""
+    from ray_tracer_amd import configs
+
+    got, why = _read_image(os.path.join(ROOT, "resources", "earthmap.jpg"))
+    assert got is not None, why
+    want = configs.load_earth()
+    assert got.shape == want.shape == (512, 1024, 3)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 3 and diff.mean() < 0.05 and np.count_nonzero(diff) < 0.03 * diff.size
+    # the texel the survey quotes: u = v = 0.5 -> pixel (512, 256) = (0, 2, 53) in libjpeg's decode
+    assert np.abs(got[256, 512].astype(int) - np.array([0, 2, 53])).max() <= 2
+    # and the scene that uses it gets an image texture of that size by default paths
+    world = api.World.generate("Earth", 10, 7, 0.0, 1.0, earth_path=os.path.join(ROOT, "resources", "earthmap.jpg"))
+    d = world.desc.contents
+    assert d.n_images == 1 and (d.images[0].width, d.images[0].height) == (1024, 512)
+
+
+def test_jpeg_reader_on_other_baseline_files_and_refusals(tmp_path):
+    from PIL import Image
+
+    y, x = np.mgrid[0:75, 0:100]
+    smooth = np.stack([128 + 100 * np.sin(x / 17.0), 128 + 100 * np.cos(y / 13.0), 40 + 2 * x], axis=-1).clip(0, 255).astype(np.uint8)
+    cases = {"444.jpg": dict(subsampling=0, quality=92), "420.jpg": dict(subsampling=2, quality=92),
+             "422_restart.jpg": dict(subsampling=1, quality=90, restart_marker_blocks=5)}
+    for name, kw in cases.items():
+        Image.fromarray(smooth).save(tmp_path / name, **kw)
+        got, why = _read_image(tmp_path / name)
+        assert got is not None, (name, why)
+        want = np.asarray(Image.open(tmp_path / name).convert("RGB"))
+        diff = np.abs(got.astype(int) - want.astype(int))
+        # subsampled chroma: replicated here, interpolated by libjpeg -- a smooth image hides most of that
+        assert got.shape == want.shape and diff.mean() < (0.1 if kw["subsampling"] == 0 else 2.5), (name, diff.mean(), diff.max())
+    Image.fromarray(smooth[:, :, 0]).save(tmp_path / "grey.jpg", quality=95)
+    got, why = _read_image(tmp_path / "grey.jpg")
+    want = np.asarray(Image.open(tmp_path / "grey.jpg").convert("RGB"))
+    assert got is not None and np.abs(got.astype(int) - want.astype(int)).max() <= 2
+    # what the decoder does not read is refused with a reason, and Texture::image then falls back to the
+    # reference's cyan error texture (texture.rs:173-177)
+    Image.fromarray(smooth).save(tmp_path / "progressive.jpg", progressive=True)
+    got, why = _read_image(tmp_path / "progressive.jpg")
+    assert got is None and "progressive" in why
+    (tmp_path / "cut.jpg").write_bytes((tmp_path / "444.jpg").read_bytes()[:300])
+    assert _read_image(tmp_path / "cut.jpg")[0] is None
+    assert _read_image(tmp_path / "missing.jpg")[0] is None
+    world = api.World.generate("Earth", 10, 7, 0.0, 1.0, earth_path=str(tmp_path / "progressive.jpg"))
+    d = world.desc.contents
+    assert d.n_images == 0 and any(tuple(d.textures[i].color) == (0.0, 1.0, 1.0) for i in range(d.n_textures))
+
+
 # ------------------------------------------------------------------ the command line
 GOOD_TOML = """
 [output]
