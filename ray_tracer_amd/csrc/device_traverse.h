@@ -41,6 +41,12 @@ __device__ __forceinline__ uint32_t mbcnt_lt(unsigned long long mask) {
 #ifndef MIRT_NODE_WIDE_LOADS
 #define MIRT_NODE_WIDE_LOADS 1  // +1.6 % on the 3,500-shape scene against seven 8-byte loads picked by address
 #endif
+// A tree too large for LDS is read from global memory as a whole: keeping its top levels in LDS makes every
+// node visit of a wave run both ways of reading (lanes above and below the cut), which costs more than the
+// LDS reads save (measured on the 3,500-shape scene: -2.6 %; the top of the tree stays in the vector L1 anyway)
+#ifndef MIRT_TOP_IN_LDS
+#define MIRT_TOP_IN_LDS 0
+#endif
 constexpr uint32_t CUR_DONE = 0x7FFFFFFFu;
 constexpr int NODE_LDS_BYTES = sizeof(CNode);  // 56
 constexpr int SHAPE_LDS_BYTES = sizeof(ShapeRec);  // 136
@@ -418,7 +424,7 @@ struct RayWalk {
         } else {
             // a tree too large for LDS: its top lives there, the rest is read from global memory
             f32x2 nx, fx, ny, fy, nz, fz;
-            if (cur < lds.n_top) {
+            if (MIRT_TOP_IN_LDS && cur < lds.n_top) {
                 const uint32_t node = (uint32_t)(size_t)lds.nodes + __umul24(cur, (uint32_t)NODE_LDS_BYTES);  // (one v_mad_u32_u24)
                 const uint32_t ax = node + cull.off[0], bx = node + (cull.off[0] ^ 8u);
                 const uint32_t ay = node + cull.off[1], by = node + (cull.off[1] ^ 8u);

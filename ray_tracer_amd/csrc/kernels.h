@@ -652,6 +652,9 @@ constexpr uint32_t PATHS_TUNING_BIG_TREE = 3u | (44u << 8) | (8u << 16) | (1u <<
 #ifndef MIRT_PARK
 #define MIRT_PARK 4
 #endif
+#ifndef MIRT_PARK_BIG
+#define MIRT_PARK_BIG 2
+#endif
 
 // A kernel argument read from the argument block (constant address space: scalar loads) at byte `offset`.
 typedef const __attribute__((address_space(4))) uint32_t* KernargWords;
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
     char* lds_shapes = lds_nodes + trav_nodes_bytes(n_top);
-    typedef RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : 2> Walk;
+    typedef RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : MIRT_PARK_BIG> Walk;
     stage_tree<PATHS_BLOCK, true, TREE_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
     const TraverseLds lds{lds_nodes, lds_shapes, n_top};
 

@@ -806,7 +806,7 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
         p.kernel = paths_kernel_for<uint16_t, true>(textures);
     } else {
         const size_t room = TRAV_LDS_BUDGET > stack + fixed ? TRAV_LDS_BUDGET - stack - fixed : 0;
-        p.n_top = (uint32_t)std::min<size_t>(scene->d.n_nodes, room / NODE_LDS_BYTES);
+        p.n_top = MIRT_TOP_IN_LDS ? (uint32_t)std::min<size_t>(scene->d.n_nodes, room / NODE_LDS_BYTES) : 0u;
         p.lds_bytes = stack + trav_nodes_bytes(p.n_top);
         p.kernel = p.stack16 ? paths_kernel_for<uint16_t, false>(textures) : paths_kernel_for<uint32_t, false>(textures);
     }
