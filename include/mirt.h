@@ -210,8 +210,8 @@ typedef struct mirt_render_opts {
     uint32_t sample_begin;   /* render samples s in [sample_begin, sample_end) of 0..spp */
     uint32_t sample_end;     /* 0 = spp */
     uint32_t paths_per_pass; /* target number of paths per pass; 0 = default (2^29 when the path kernel
-                              * runs from the camera ray, 32 B of device memory per path, but at most a
-                              * quarter of the free device memory; 2^23 otherwise, 173 B per path) */
+                              * runs from the camera ray, 32 B of device memory per path; 2^26 otherwise,
+                              * 173 B per path; either way at most a quarter of the free device memory) */
     int32_t profile;         /* 1 = time each kernel class with HIP events (fills mirt_stats.ms_*) */
     /* Tile split across devices: of the pixel range, cut into tiles of tile_size
      * consecutive pixels, only tiles t with t % tile_count == tile_index are

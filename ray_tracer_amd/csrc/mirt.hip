@@ -936,18 +936,20 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
 
     // Default pass: 2^29 paths when the path kernel runs from the camera ray (17 GB of radiance
     // records: each launch ends with a tail of a few deep paths, ~0.8 ms on RTIOW, so few large
-    // launches beat many small ones: +7.5 % over 2^26), at most a quarter of the device memory that is
-    // free; 2^23 for the queue pipeline (173 B per path).
-    uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 29) : (1ull << 23));
+    // launches beat many small ones: +7.5 % over 2^26); 2^26 for the per-bounce pipeline (173 B of path state
+    // per path + the record: against 2^23 an eighth of the launches, most of which find almost empty queues:
+    // 1 369 instead of 787 Msamples/s on RTIOW); either way at most a quarter of the device memory that is free.
+    uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 29) : (1ull << 26));
+    const size_t bytes_per_path = from_start ? sizeof(double4) : 208;
     if (static_scratch) target = std::min<uint64_t>(target, STATIC_PASS_PATHS);
-    if (!o.paths_per_pass && from_start && !static_scratch) {
+    if (!o.paths_per_pass && !static_scratch) {
         size_t free_bytes = 0, total_bytes = 0;
         if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
             {
                 std::lock_guard<std::mutex> lock(scene->ws_mutex);
                 free_bytes += scene->ws_bytes;  // what the scene already holds for this purpose
             }
-            while (target > (1ull << 22) && target * sizeof(double4) > free_bytes / 4) target >>= 1;
+            while (target > (1ull << 22) && target * bytes_per_path > free_bytes / 4) target >>= 1;
         }
     }
     uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, target / n_pixels));
