@@ -56,7 +56,8 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=0, help="override the configuration's samples per pixel")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--split", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--split", default=None, choices=["tile", "sample"],
+                    help="how N > 1 GPUs share the frame; default: tile, and sample for C5 (as BASELINE.json names them)")
     ap.add_argument("--paths-per-pass", type=int, default=0)
     ap.add_argument("--handover", type=int, default=0,
                     help="mirt_render_opts.handover_bounce: 0 = path kernel from the camera ray (default), N = launches per "
@@ -116,6 +117,8 @@ def launch_ranks(n):
 
 def main():
     args = parse_args()
+    if args.split is None:
+        args.split = "sample" if args.config == "C5" else "tile"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
