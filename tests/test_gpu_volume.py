@@ -55,3 +55,53 @@ def test_full_size_frames_path_kernel_against_pipeline(name, worlds):
         assert paths.std() > 5  # an image
     finally:
         scene.close()
+
+
+def test_a_scene_of_seventy_thousand_shapes(oracle):
+    """More than 65 535 tree nodes: the traversal kernels then keep 32-bit stack entries (other template
+    instances than every other test runs), the tree and the records are read from global memory, and the
+    reference's own tree is 17 levels deep.  Closest hits on 300 000 rays through both traversals, and a
+    small render, against the oracle."""
+    import scene_util as su
+
+    rng = np.random.default_rng(77)
+    n = 70_000
+    centres = rng.uniform(-60.0, 60.0, (n, 3))
+    sizes = rng.uniform(0.2, 1.2, n)
+    shapes = []
+    for k in range(n):
+        c, r = centres[k], sizes[k]
+        kind = k % 4
+        if kind == 0:
+            shapes.append(su.shape(abi.SHAPE_CUBE, k % 3, *(c - r), *(c + r)))
+        elif kind == 1:
+            shapes.append(su.shape(abi.SHAPE_XY_RECT + k % 3, k % 3, c[0], c[0] + 2 * r, c[1], c[1] + 2 * r, c[2]))
+        elif kind == 2 and k % 8 == 2:
+            shapes.append(su.moving_sphere(c, c + rng.uniform(-0.5, 0.5, 3), r, 0.0, 1.0, k % 3))
+        else:
+            shapes.append(su.sphere(*c, r, k % 3))
+    textures = [su.constant(0.7, 0.3, 0.3), su.constant(0.9, 0.9, 0.9)]
+    materials = [su.material(abi.MAT_LAMBERTIAN, 0), su.material(abi.MAT_METAL, albedo=(0.8, 0.8, 0.9), param=0.1),
+                 su.material(abi.MAT_DIELECTRIC, param=1.5)]
+    built = su.Built(shapes, materials, textures, seed=11)
+    assert built.desc.n_nodes == 2 * n - 1 > 65535
+    m = 300_000
+    rays = np.zeros(m, dtype=api.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-80.0, 80.0, (m, 3))
+    rays["direction"] = (rng.uniform(-50.0, 50.0, (m, 3)) - rays["origin"]) * rng.uniform(0.2, 2.0, (m, 1))
+    rays["time"] = rng.uniform(0.0, 1.0, m)
+    ref, _ = oracle.intersect(built.desc, rays)
+    assert np.count_nonzero(ref["prim"] >= 0) > m // 2
+    scene = api.Scene(built.desc)
+    try:
+        _compare(scene.hit(rays), ref, "70 000 shapes, fast")
+        _compare(scene.hit(rays, traversal=abi.TRAVERSE_REFERENCE), ref, "70 000 shapes, reference-order")
+        w, h, spp = 96, 54, 4
+        cam = api.Camera.new((0.0, 5.0, 110.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, w / h, 0.0, 10.0, 0.0, 1.0)
+        want, _, ctr, _ = oracle.render(built.desc, cam, api.SKY, w, h, spp)
+        got, st = api.render_world(api.SKY, scene, cam, w, h, spp, return_stats=True)
+        assert st["segments"] == ctr["segments"]
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert diff.max() <= 1 and np.count_nonzero(diff) <= 0.002 * diff.size
+    finally:
+        scene.close()
