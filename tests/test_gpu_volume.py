@@ -57,15 +57,15 @@ def test_full_size_frames_path_kernel_against_pipeline(name, worlds):
         scene.close()
 
 
-def test_a_scene_of_seventy_thousand_shapes(oracle):
-    """More than 65 535 tree nodes: the traversal kernels then keep 32-bit stack entries (other template
-    instances than every other test runs), the tree and the records are read from global memory, and the
-    reference's own tree is 17 levels deep.  Closest hits on 300 000 rays through both traversals, and a
-    small render, against the oracle."""
+@pytest.mark.parametrize("n", [3_000, 70_000])
+def test_scenes_too_large_for_lds(n, oracle):
+    """3 000 shapes: tree and records are read from global memory (16-bit stack entries, plain textures: a
+    kernel instance no benchmark scene selects).  70 000 shapes: more than 65 535 tree nodes, so the
+    traversal kernels keep 32-bit stack entries (again other instances), and the reference's own tree is 17
+    levels deep.  Closest hits on 300 000 rays through both traversals, and a small render, against the oracle."""
     import scene_util as su
 
     rng = np.random.default_rng(77)
-    n = 70_000
     centres = rng.uniform(-60.0, 60.0, (n, 3))
     sizes = rng.uniform(0.2, 1.2, n)
     shapes = []
@@ -84,18 +84,18 @@ def test_a_scene_of_seventy_thousand_shapes(oracle):
     materials = [su.material(abi.MAT_LAMBERTIAN, 0), su.material(abi.MAT_METAL, albedo=(0.8, 0.8, 0.9), param=0.1),
                  su.material(abi.MAT_DIELECTRIC, param=1.5)]
     built = su.Built(shapes, materials, textures, seed=11)
-    assert built.desc.n_nodes == 2 * n - 1 > 65535
+    assert built.desc.n_nodes == 2 * n - 1 and (n < 10_000 or built.desc.n_nodes > 65535)
     m = 300_000
     rays = np.zeros(m, dtype=api.RAY_DTYPE)
     rays["origin"] = rng.uniform(-80.0, 80.0, (m, 3))
     rays["direction"] = (rng.uniform(-50.0, 50.0, (m, 3)) - rays["origin"]) * rng.uniform(0.2, 2.0, (m, 1))
     rays["time"] = rng.uniform(0.0, 1.0, m)
     ref, _ = oracle.intersect(built.desc, rays)
-    assert np.count_nonzero(ref["prim"] >= 0) > m // 2
+    assert np.count_nonzero(ref["prim"] >= 0) > m // 8
     scene = api.Scene(built.desc)
     try:
-        _compare(scene.hit(rays), ref, "70 000 shapes, fast")
-        _compare(scene.hit(rays, traversal=abi.TRAVERSE_REFERENCE), ref, "70 000 shapes, reference-order")
+        _compare(scene.hit(rays), ref, f"{n} shapes, fast")
+        _compare(scene.hit(rays, traversal=abi.TRAVERSE_REFERENCE), ref, f"{n} shapes, reference-order")
         w, h, spp = 96, 54, 4
         cam = api.Camera.new((0.0, 5.0, 110.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, w / h, 0.0, 10.0, 0.0, 1.0)
         want, _, ctr, _ = oracle.render(built.desc, cam, api.SKY, w, h, spp)
