@@ -623,7 +623,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, Paths P, RenderParam
 // random numbers are a function of (pixel, sample, bounce) alone.
 // Workgroup size and waves per SIMD by texture level (registers: 128 / 128 / 160 / 168 VGPRs: four waves per SIMD, or three): one
 // workgroup fills the CU and shares one copy of the tree -- all of it with the shapes' records
-// (TREE_IN_LDS), or as many nodes from the top as fit.
+// (TREE_LDS), or its nodes alone when only they fit (TREE_NODES_LDS: +5..7 % on scenes of 900-1 900 shapes against
+// reading them from global memory), or nothing of it (TREE_GLOBAL).
 __host__ __device__ constexpr int paths_waves(int textures) { return textures <= TEXTURES_CHECKER ? 4 : 3; }
 __host__ __device__ constexpr int paths_block(int textures) { return 256 * paths_waves(textures); }
 // Scheduling parameters of k_paths (`tuning`):
@@ -673,11 +674,18 @@ __device__ __forceinline__ T load_kernarg(KernargWords args, size_t offset) {
 static_assert(sizeof(DScene) % 8 == 0 && sizeof(Paths) % 8 == 0 && alignof(DScene) == 8 && alignof(Paths) == 8 && alignof(RenderParams) == 8,
               "k_paths finds its second and third argument at sizeof(DScene) and sizeof(DScene) + sizeof(Paths) of the argument block");
 
-template <class StackT, int TEXTURES, bool TREE_IN_LDS>
+// TREE: where the culling tree and the shapes' records are read from.
+enum : int {
+    TREE_GLOBAL = 0,     // both from global memory
+    TREE_LDS = 1,        // both staged in LDS
+    TREE_NODES_LDS = 2   // the nodes in LDS, the records (2.4 times their size) from global memory
+};
+template <class StackT, int TEXTURES, int TREE>
 __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(
     DScene sc, Paths P, RenderParams rp, uint32_t bounce0, uint32_t stack_levels, uint32_t tuning, uint32_t n_top) {
     constexpr int PATHS_BLOCK = paths_block(TEXTURES);
     constexpr bool HAS_NOISE = TEXTURES >= TEXTURES_ALL;
+    constexpr bool TREE_IN_LDS = TREE == TREE_LDS, NODES_IN_LDS = TREE != TREE_GLOBAL;
     // dynamic LDS: [level][PATHS_BLOCK] stack entries, the first n_top nodes of the tree (TREE_IN_LDS: all of
     // them), and (TREE_IN_LDS) the shapes' records
     extern __shared__ __align__(16) char smem[];
@@ -700,7 +708,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
     char* lds_shapes = lds_nodes + trav_nodes_bytes(n_top);
-    typedef RayWalk<PATHS_BLOCK, StackT, TREE_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : MIRT_PARK_BIG> Walk;
+    typedef RayWalk<PATHS_BLOCK, StackT, NODES_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : MIRT_PARK_BIG> Walk;
+    static_assert(!Walk::PACKED || TREE_IN_LDS, "16-bit parked references need the at most 1 024 shapes of a tree that is in LDS as a whole");
     stage_tree<PATHS_BLOCK, true, TREE_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
     const TraverseLds lds{lds_nodes, lds_shapes, n_top};
 

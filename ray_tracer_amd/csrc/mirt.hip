@@ -711,6 +711,11 @@ int mirt_camera_rays(const mirt_camera* camera, uint32_t width, uint32_t height,
 }  // extern "C"
 
 // ------------------------------------------------------------------ render
+#ifndef MIRT_NODES_IN_LDS
+#define MIRT_NODES_IN_LDS 1
+#endif
+
+
 namespace {
 
 struct EventTimer {
@@ -767,6 +772,7 @@ int blocks_per_cu(K kernel, int fallback) {
 struct PathsPlan {
     bool stack16 = true;
     bool tree_in_lds = false;
+    bool nodes_in_lds = false;  // the nodes alone (records from global memory)
     int block = 256;
     size_t lds_bytes = 0;
     uint32_t levels = 1;
@@ -775,7 +781,7 @@ struct PathsPlan {
     const void* kernel = nullptr;
 };
 
-template <class StackT, bool TREE>
+template <class StackT, int TREE>
 const void* paths_kernel_for(int textures) {
     switch (textures) {
         case TEXTURES_CONSTANT: return (const void*)k_paths<StackT, TEXTURES_CONSTANT, TREE>;
@@ -803,12 +809,20 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     if (p.tree_in_lds) {
         p.n_top = scene->d.n_nodes;
         p.lds_bytes = stack + nodes + recs;
-        p.kernel = paths_kernel_for<uint16_t, true>(textures);
+        p.kernel = paths_kernel_for<uint16_t, TREE_LDS>(textures);
     } else {
         const size_t room = TRAV_LDS_BUDGET > stack + fixed ? TRAV_LDS_BUDGET - stack - fixed : 0;
-        p.n_top = MIRT_TOP_IN_LDS ? (uint32_t)std::min<size_t>(scene->d.n_nodes, room / NODE_LDS_BYTES) : 0u;
-        p.lds_bytes = stack + trav_nodes_bytes(p.n_top);
-        p.kernel = p.stack16 ? paths_kernel_for<uint16_t, false>(textures) : paths_kernel_for<uint32_t, false>(textures);
+        if (MIRT_NODES_IN_LDS && p.stack16 && scene->d.n_nodes > 0 && nodes <= room) {
+            // the nodes fit on their own: every node visit from LDS, the records from global memory
+            p.nodes_in_lds = true;
+            p.n_top = scene->d.n_nodes;
+            p.lds_bytes = stack + nodes;
+            p.kernel = paths_kernel_for<uint16_t, TREE_NODES_LDS>(textures);
+        } else {
+            p.n_top = MIRT_TOP_IN_LDS ? (uint32_t)std::min<size_t>(scene->d.n_nodes, room / NODE_LDS_BYTES) : 0u;
+            p.lds_bytes = stack + trav_nodes_bytes(p.n_top);
+            p.kernel = p.stack16 ? paths_kernel_for<uint16_t, TREE_GLOBAL>(textures) : paths_kernel_for<uint32_t, TREE_GLOBAL>(textures);
+        }
     }
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(p.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);

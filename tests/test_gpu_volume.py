@@ -57,9 +57,10 @@ def test_full_size_frames_path_kernel_against_pipeline(name, worlds):
         scene.close()
 
 
-@pytest.mark.parametrize("n", [3_000, 70_000])
+@pytest.mark.parametrize("n", [1_500, 3_000, 70_000])
 def test_scenes_too_large_for_lds(n, oracle):
-    """3 000 shapes: tree and records are read from global memory (16-bit stack entries, plain textures: a
+    """1 500 shapes: the nodes fit LDS, the records do not (a third way of reading the tree).
+    3 000 shapes: tree and records are read from global memory (16-bit stack entries, plain textures: a
     kernel instance no benchmark scene selects).  70 000 shapes: more than 65 535 tree nodes, so the
     traversal kernels keep 32-bit stack entries (again other instances), and the reference's own tree is 17
     levels deep.  Closest hits on 300 000 rays through both traversals, and a small render, against the oracle."""
