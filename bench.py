@@ -153,11 +153,6 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
     n_ranks = args.gpus if args.single_process else world_size  # shares the frame is cut into
-    if args.split == "sample" and n_ranks > 1:
-        probe = configs.ALL[args.config]
-        if (args.spp or probe.spp) < n_ranks:
-            raise SystemExit(f"--split sample needs at least one sample per rank: spp {(args.spp or probe.spp)} < {n_ranks} ranks")
-
     cfg = configs.ALL[args.config]
     if args.spp or args.width or args.height:
         cfg = cfg.scaled(args.width or cfg.width, args.height or cfg.height, args.spp or cfg.spp)
@@ -165,6 +160,8 @@ def main():
     if n_ranks > 1 and args.scaling == "weak":
         cfg = cfg.scaled(cfg.width, cfg.height, cfg.spp * n_ranks)
     W, H, spp = cfg.width, cfg.height, cfg.spp
+    if args.split == "sample" and n_ranks > 1 and spp < n_ranks:
+        raise SystemExit(f"--split sample needs at least one sample per rank: spp {spp} < {n_ranks} ranks")
     world = cfg.world()
     cam = cfg.camera()
     t_upload = time.perf_counter()
