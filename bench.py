@@ -88,7 +88,15 @@ def cpu_baseline(cfg, world, seconds):
     spp = int(max(1, min(cfg.spp, seconds / max(per_frame_spp1, 1e-3))))
     _, _, ctr, secs = oracle_lib.render(world.desc, cam, cfg.background, cfg.width, cfg.height, spp)
     samples = cfg.width * cfg.height * spp
+    extra = {}
+    if cfg.name.startswith("C2"):
+        # the reference's own CPU-runnable case, exactly: the same scene at 400x225, 10 spp (best of three: it takes 0.1 s)
+        from ray_tracer_amd import configs
+        c1 = configs.C1
+        runs = [oracle_lib.render(world.desc, c1.camera(), c1.background, c1.width, c1.height, c1.spp)[3] for _ in range(3)]
+        extra["c1_400x225x10_msamples_per_s"] = c1.width * c1.height * c1.spp / min(runs) / 1e6
     return {
+        **extra,
         "value": samples / secs / 1e6,
         "unit": "Msamples/s",
         "cores": threads,
