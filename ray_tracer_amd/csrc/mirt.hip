@@ -634,7 +634,7 @@ hipError_t launch_traverse_with_stats(const mirt_scene* scene, const IntersectIo
 
 extern "C" {
 
-int mirt_intersect_device(const mirt_scene* scene, const mirt_ray* d_rays, size_t n, double t_min, double t_max,
+static int mirt_intersect_device_body(const mirt_scene* scene, const mirt_ray* d_rays, size_t n, double t_min, double t_max,
                           int use_bvh, int traversal, mirt_hit* d_hits) {
     if (!scene) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene is null");
     if (n == 0) return MIRT_OK;
@@ -665,7 +665,7 @@ int mirt_intersect_device(const mirt_scene* scene, const mirt_ray* d_rays, size_
     return MIRT_OK;
 }
 
-int mirt_intersect(const mirt_scene* scene, const mirt_ray* rays, size_t n, double t_min, double t_max, int use_bvh,
+static int mirt_intersect_body(const mirt_scene* scene, const mirt_ray* rays, size_t n, double t_min, double t_max, int use_bvh,
                    int traversal, mirt_hit* hits) {
     if (!scene) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene is null");
     if (n == 0) return MIRT_OK;
@@ -680,13 +680,13 @@ int mirt_intersect(const mirt_scene* scene, const mirt_ray* rays, size_t n, doub
     HIP_TRY(arena.alloc(&d_rays, n));
     HIP_TRY(arena.alloc(&d_hits, n));
     HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(mirt_ray), hipMemcpyHostToDevice));
-    rc = mirt_intersect_device(scene, d_rays, n, t_min, t_max, use_bvh, traversal, d_hits);
+    rc = mirt_intersect_device_body(scene, d_rays, n, t_min, t_max, use_bvh, traversal, d_hits);
     if (rc != MIRT_OK) return rc;
     HIP_TRY(hipMemcpy(hits, d_hits, n * sizeof(mirt_hit), hipMemcpyDeviceToHost));
     return MIRT_OK;
 }
 
-int mirt_camera_rays(const mirt_camera* camera, uint32_t width, uint32_t height, uint32_t pixel_begin,
+static int mirt_camera_rays_body(const mirt_camera* camera, uint32_t width, uint32_t height, uint32_t pixel_begin,
                      uint32_t pixel_end, uint32_t sample, uint64_t seed, int device, mirt_ray* rays) {
     if (!camera || !rays) return fail(MIRT_ERR_INVALID_ARGUMENT, "camera or rays is null");
     if (width == 0 || height == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image");
@@ -1163,7 +1163,7 @@ extern "C" {
 int mirt_render_accumulate(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
                            uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
                            const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {
-    return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats);
+    return no_throw([&] { return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats); });
 }
 
 static int accum_values(uint32_t width, uint32_t height, size_t* n) {
@@ -1225,7 +1225,7 @@ int mirt_accum_write(double* d_accum, uint32_t width, uint32_t height, int devic
 int mirt_render_accumulate_static(const mirt_scene* scene, const mirt_camera* camera, const double background[3],
                                   uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed,
                                   const mirt_render_opts* opts, double* d_accum, mirt_stats* stats) {
-    return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats, true);
+    return no_throw([&] { return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats, true); });
 }
 
 static int resolve_tiles_body(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
@@ -1279,7 +1279,7 @@ int mirt_resolve(const double* d_accum, uint32_t width, uint32_t height, uint32_
     return mirt_resolve_tiles(d_accum, width, height, spp, pixel_begin, pixel_end, 0, 1, 0, device, out_rgb);
 }
 
-int mirt_render(const mirt_scene* scene, const mirt_camera* camera, const double background[3], uint32_t width,
+static int mirt_render_body(const mirt_scene* scene, const mirt_camera* camera, const double background[3], uint32_t width,
                 uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
                 uint8_t* out_rgb, mirt_stats* stats) {
     if (!scene || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
@@ -1319,6 +1319,31 @@ int mirt_render(const mirt_scene* scene, const mirt_camera* camera, const double
     if (rc != MIRT_OK) return rc;
     if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     return MIRT_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int mirt_intersect_device(const mirt_scene* scene, const mirt_ray* d_rays, size_t n, double t_min, double t_max,
+                          int use_bvh, int traversal, mirt_hit* d_hits) {
+    return no_throw([&] { return mirt_intersect_device_body(scene, d_rays, n, t_min, t_max, use_bvh, traversal, d_hits); });
+}
+
+int mirt_intersect(const mirt_scene* scene, const mirt_ray* rays, size_t n, double t_min, double t_max, int use_bvh,
+                   int traversal, mirt_hit* hits) {
+    return no_throw([&] { return mirt_intersect_body(scene, rays, n, t_min, t_max, use_bvh, traversal, hits); });
+}
+
+int mirt_camera_rays(const mirt_camera* camera, uint32_t width, uint32_t height, uint32_t pixel_begin,
+                     uint32_t pixel_end, uint32_t sample, uint64_t seed, int device, mirt_ray* rays) {
+    return no_throw([&] { return mirt_camera_rays_body(camera, width, height, pixel_begin, pixel_end, sample, seed, device, rays); });
+}
+
+int mirt_render(const mirt_scene* scene, const mirt_camera* camera, const double background[3], uint32_t width,
+                uint32_t height, uint32_t spp, uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
+                uint8_t* out_rgb, mirt_stats* stats) {
+    return no_throw([&] { return mirt_render_body(scene, camera, background, width, height, spp, max_depth, seed, opts, out_rgb, stats); });
 }
 
 }  // extern "C"
