@@ -173,7 +173,7 @@ def main():
     world = cfg.world()
     cam = cfg.camera()
     t_upload = time.perf_counter()
-    scene = api.Scene(world)  # scene resident in HBM before the timed region
+    scene = api.Scene(world, device=device_index)  # scene resident in HBM before the timed region
     scene_upload_ms = (time.perf_counter() - t_upload) * 1e3  # culling-tree build on the host + copies; outside `value`
     rank_scenes = [scene]
     if args.single_process and args.gpus > 1:
@@ -218,7 +218,7 @@ def main():
                 if rank == 0:
                     accum.copy_(host)
             if rank == 0:
-                api.resolve(accum.data_ptr(), W, H, spp, out=out)
+                api.resolve(accum.data_ptr(), W, H, spp, out=out, device=device_index)
         return st
 
     for _ in range(args.warmup):
