@@ -535,6 +535,84 @@ struct RayWalk {
     }
 };
 
+// The same interface for a scene of a handful of shapes (the Cornell box has eight): no tree at all.
+// One "shape test" step tests EVERY shape, in index order, for all lanes that wait for it -- the loop
+// and the shape's kind are the same for the whole wave (scalar branches, the shape's parameters in
+// scalar registers, read through the constant address space: they are written before the launch and
+// never after), so the wave never splits over which shape or which kind of shape comes next.  Walking
+// a tree of eight shapes costs more in divergence than it saves in tests.
+// The closest hit among all shapes is then confirmed against the reference's boxes exactly as
+// RayWalk does it (confirm / begin_careful), which is why the culling constants are still prepared.
+template <int BLOCK, bool SHAPES_IN_LDS>
+struct ScanWalk {
+    static constexpr uint32_t SIDE_MASK = 15u, CLASS_SHIFT = 4, TK_SHIFT = 7;
+    static constexpr bool PACKED = false;
+    RayD r;
+    CullRay cull;
+    HitRec best;
+    bool pending;  // the scan of this ray is still to be done
+    bool careful;  // second scan: a hit counts only if its shape's gates pass
+
+    __device__ __forceinline__ void reset() {
+        pending = false;
+        careful = false;
+        best = HitRec{0.0, -1, 0};
+    }
+    __device__ __forceinline__ bool wants_node() const { return false; }
+    __device__ __forceinline__ bool wants_leaf() const { return pending; }
+    __device__ __forceinline__ unsigned long long vote_node() const { return 0ull; }
+    __device__ __forceinline__ unsigned long long vote_leaf() const { return __builtin_amdgcn_ballot_w64(pending); }
+    __device__ __forceinline__ bool finished() const { return !pending; }
+
+    __device__ __forceinline__ void begin(const DScene& sc, const RayD& ray, double t_min, double t_max) {
+        r = ray;
+        // (the constants serve sure_to_cross only, which holds for any ray they are `tame` for)
+        cull.set(r, r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z);
+        careful = false;
+        pending = true;
+        best = HitRec{0.0, -1, 0};
+    }
+    __device__ __forceinline__ bool confirm(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
+        if (careful || best.prim < 0) return true;
+        const ShapeRec* rec = SHAPES_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)best.prim * SHAPE_LDS_BYTES)
+                                            : sc.recs + best.prim;
+        if (cull.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) return true;
+        return gates_pass(sc.gates, sc.gate_of, (uint32_t)best.prim, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max);
+    }
+    __device__ __forceinline__ void begin_careful(const DScene& sc, double t_min, double t_max) {
+        careful = true;
+        pending = true;
+        best = HitRec{0.0, -1, 0};
+    }
+    template <class StackT>
+    __device__ __forceinline__ void node_step(const DScene&, const TraverseLds&, StackT*, uint32_t, double) {}
+
+    __device__ __forceinline__ void leaf_step(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
+        typedef const __attribute__((address_space(4))) ShapeRec* ConstRecs;
+        typedef const __attribute__((address_space(4))) DShape* ConstShapes;
+        const ConstRecs recs = (ConstRecs)(uintptr_t)sc.recs;
+        const ConstShapes shapes = (ConstShapes)(uintptr_t)sc.shapes;
+        const uint32_t n = sc.n_shapes;
+        const double dd = dot(r.d, r.d);
+        for (uint32_t index = 0; index < n; ++index) {
+            double p[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) p[k] = recs[index].f[k];
+            const uint32_t tk = shapes[index].tk, cls = shapes[index].cls;
+            double t;
+            int side;
+            if (tshape_hit(p, tk, r, dd, t_min, t_max, &t, &side)) {
+                // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74) -- the later one here
+                if (best.prim < 0 || t <= best.t) {
+                    if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max))
+                        best = HitRec{t, (int32_t)index, (int32_t)((uint32_t)side | (cls | tk << 3) << CLASS_SHIFT)};
+                }
+            }
+        }
+        pending = false;
+    }
+};
+
 // Per-wave persistent traversal of a queue of rays.
 //   Io::count()                      number of rays in the queue
 //   Io::load(i, &ray, &cookie)       ray i of the queue

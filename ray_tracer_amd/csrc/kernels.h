@@ -30,6 +30,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_shade.h"
 #include "device_traverse.h"
 
@@ -645,6 +647,13 @@ constexpr uint32_t PATHS_TUNING_DEFAULT = 1u | (48u << 8) | (20u << 16) | (3u <<
 // empty ones leaves the others idle for longer (3,500-shape scene: +4 %; scenes whose tree is in LDS
 // lose 1-3 % with these)
 constexpr uint32_t PATHS_TUNING_BIG_TREE = 3u | (44u << 8) | (8u << 16) | (1u << 30);
+// no tree (ScanWalk): after a scan every lane is ready for shading, so shading never waits; the refill
+// threshold is what there is to choose
+constexpr uint32_t PATHS_TUNING_SCAN = 1u | (1u << 8) | (16u << 16) | (3u << 30);
+// Most shapes a scene may have to be rendered without a tree.
+#ifndef MIRT_SCAN_MAX_SHAPES
+#define MIRT_SCAN_MAX_SHAPES 16
+#endif
 // Shapes a walk may hold parked for later shape tests while it goes on visiting nodes: with 4 (node
 // visits allowed while at most 2 are parked) a lane can take part in whichever of the two steps the
 // wave runs next, at the price of some visits a found hit would have culled: +4 % RTIOW, +11 % Cornell
@@ -678,14 +687,17 @@ static_assert(sizeof(DScene) % 8 == 0 && sizeof(Paths) % 8 == 0 && alignof(DScen
 enum : int {
     TREE_GLOBAL = 0,     // both from global memory
     TREE_LDS = 1,        // both staged in LDS
-    TREE_NODES_LDS = 2   // the nodes in LDS, the records (2.4 times their size) from global memory
+    TREE_NODES_LDS = 2,  // the nodes in LDS, the records (2.4 times their size) from global memory
+    TREE_SCAN = 3        // a handful of shapes: no tree, every ray is tested against every shape (ScanWalk)
 };
 template <class StackT, int TEXTURES, int TREE>
 __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(
     DScene sc, Paths P, RenderParams rp, uint32_t bounce0, uint32_t stack_levels, uint32_t tuning, uint32_t n_top) {
     constexpr int PATHS_BLOCK = paths_block(TEXTURES);
     constexpr bool HAS_NOISE = TEXTURES >= TEXTURES_ALL;
-    constexpr bool TREE_IN_LDS = TREE == TREE_LDS, NODES_IN_LDS = TREE != TREE_GLOBAL;
+    constexpr bool SCAN = TREE == TREE_SCAN;
+    constexpr bool TREE_IN_LDS = TREE == TREE_LDS, NODES_IN_LDS = TREE == TREE_LDS || TREE == TREE_NODES_LDS;
+    constexpr bool RECS_IN_LDS = TREE_IN_LDS || SCAN;  // the shapes' records, as shading reads them
     // dynamic LDS: [level][PATHS_BLOCK] stack entries, the first n_top nodes of the tree (TREE_IN_LDS: all of
     // them), and (TREE_IN_LDS) the shapes' records
     extern __shared__ __align__(16) char smem[];
@@ -708,9 +720,10 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
     char* lds_shapes = lds_nodes + trav_nodes_bytes(n_top);
-    typedef RayWalk<PATHS_BLOCK, StackT, NODES_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : MIRT_PARK_BIG> Walk;
+    typedef RayWalk<PATHS_BLOCK, StackT, NODES_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : MIRT_PARK_BIG> TreeWalk;
+    typedef typename std::conditional<SCAN, ScanWalk<PATHS_BLOCK, true>, TreeWalk>::type Walk;
     static_assert(!Walk::PACKED || TREE_IN_LDS, "16-bit parked references need the at most 1 024 shapes of a tree that is in LDS as a whole");
-    stage_tree<PATHS_BLOCK, true, TREE_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
+    stage_tree<PATHS_BLOCK, !SCAN, RECS_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
     const TraverseLds lds{lds_nodes, lds_shapes, n_top};
 
     const Counters C{rp.max_depth};
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                     cls = ((uint32_t)h.side >> walk.CLASS_SHIFT) & 7u;
                     tk = ((uint32_t)h.side >> walk.TK_SHIFT) & 7u;
                     hit_ref = (uint32_t)h.prim | (((uint32_t)h.side & walk.SIDE_MASK) << HIT_SIDE_SHIFT);
-                    rec = TREE_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)h.prim * SHAPE_LDS_BYTES) : sc.recs + h.prim;
+                    rec = RECS_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)h.prim * SHAPE_LDS_BYTES) : sc.recs + h.prim;
                 }
                 const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, in_sphere, stream, bounce, last, background, lds_tables, n_staged,
                                                            shade_clock);

@@ -773,6 +773,7 @@ struct PathsPlan {
     bool stack16 = true;
     bool tree_in_lds = false;
     bool nodes_in_lds = false;  // the nodes alone (records from global memory)
+    bool scan = false;          // no tree: every shape tested for every ray
     int block = 256;
     size_t lds_bytes = 0;
     uint32_t levels = 1;
@@ -806,7 +807,19 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     // of it and the shapes' records if they fit, else as many nodes from the top as do
     // (REF16_MAX_SHAPES: the kernel with the tree in LDS parks shapes as 16-bit references)
     p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && scene->d.n_shapes <= REF16_MAX_SHAPES && stack + nodes + recs + fixed <= TRAV_LDS_BUDGET;
-    if (p.tree_in_lds) {
+    // development aid: MIRT_SCAN_MAX overrides the largest scene rendered without a tree
+    static const uint32_t scan_max = [] {
+        const char* s = std::getenv("MIRT_SCAN_MAX");
+        return s ? (uint32_t)std::strtoul(s, nullptr, 0) : (uint32_t)MIRT_SCAN_MAX_SHAPES;
+    }();
+    if (scene->d.n_shapes <= scan_max) {
+        p.scan = true;
+        p.tree_in_lds = false;
+        p.levels = 0;
+        p.n_top = 0;
+        p.lds_bytes = recs;
+        p.kernel = paths_kernel_for<uint16_t, TREE_SCAN>(textures);
+    } else if (p.tree_in_lds) {
         p.n_top = scene->d.n_nodes;
         p.lds_bytes = stack + nodes + recs;
         p.kernel = paths_kernel_for<uint16_t, TREE_LDS>(textures);
@@ -846,7 +859,10 @@ hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Pa
         const char* s = std::getenv("MIRT_PATHS_TUNING");
         return s ? (uint32_t)std::strtoul(s, nullptr, 0) : 0u;
     }();
-    const uint32_t tuning_default = tuning_override ? tuning_override : plan.tree_in_lds ? PATHS_TUNING_DEFAULT : PATHS_TUNING_BIG_TREE;
+    const uint32_t tuning_default = tuning_override ? tuning_override
+                                    : plan.scan     ? PATHS_TUNING_SCAN
+                                    : plan.tree_in_lds ? PATHS_TUNING_DEFAULT
+                                                       : PATHS_TUNING_BIG_TREE;
     DScene sc = scene->d;
     Paths paths = P;
     RenderParams params = rp;
