@@ -394,6 +394,65 @@ struct Builder {
 
 }  // namespace accel
 
+// The items of a scene small enough to be rendered without a tree (device_scene.h, ScanItem) and
+// their culling boxes in pairs.  `ref_bits` as for build_fast_tree.  False: more than
+// SCAN_MAX_ITEMS items (or shapes than an item's reference can name).
+inline bool build_scan_items(const mirt_scene_desc* desc, const std::vector<ShapeRec>& recs, const uint32_t* ref_bits,
+                             std::vector<ScanBoxes>* pairs, std::vector<ScanItem>* items) {
+    using namespace accel;
+    pairs->clear();
+    items->clear();
+    if (desc->n_shapes > 256) return false;
+    std::vector<Box> boxes;
+    auto add = [&](uint32_t shape, uint32_t exact_kind, uint32_t side, const double* f, int n_f, const Box& box) {
+        ScanItem it;
+        std::memset(&it, 0, sizeof it);
+        std::memcpy(it.f, f, sizeof(double) * n_f);
+        const uint32_t tk = (ref_bits[shape] >> REF_KIND_SHIFT) & 7u, cls = (ref_bits[shape] >> REF_CLASS_SHIFT) & 7u;
+        it.ref = shape | exact_kind << 8 | (side | cls << 4 | tk << 7) << 16;
+        items->push_back(it);
+        boxes.push_back(box);
+    };
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        const mirt_shape& s = desc->shapes[i];
+        const uint32_t tk = (ref_bits[i] >> REF_KIND_SHIFT) & 7u;
+        if (tk != TK_CUBE) {
+            add(i, tk, 0, recs[i].f, tk == TK_SPHERE || tk == TK_MOVING_SPHERE ? 9 : 5, shape_box(s));
+            continue;
+        }
+        // the six faces in the order of hittable.rs:432-445 (cube_hit, device_intersect.h)
+        const double p0x = s.f[0], p0y = s.f[1], p0z = s.f[2], p1x = s.f[3], p1y = s.f[4], p1z = s.f[5];
+        const double faces[6][5] = {{p0x, p1x, p0y, p1y, p0z}, {p0x, p1x, p0y, p1y, p1z}, {p0x, p1x, p0z, p1z, p1y},
+                                    {p0x, p1x, p0z, p1z, p0y}, {p0y, p1y, p0z, p1z, p1x}, {p0y, p1y, p0z, p1z, p0x}};
+        const uint32_t kinds[6] = {TK_XY_RECT, TK_XY_RECT, TK_XZ_RECT, TK_XZ_RECT, TK_YZ_RECT, TK_YZ_RECT};
+        for (uint32_t side = 0; side < 6; ++side) {
+            mirt_shape face;
+            std::memset(&face, 0, sizeof face);
+            face.kind = kinds[side];  // (TraverseKind and MIRT_SHAPE_* number the rects alike)
+            std::memcpy(face.f, faces[side], sizeof faces[side]);
+            add(i, kinds[side], side, faces[side], 5, shape_box(face));
+        }
+    }
+    if (items->size() > SCAN_MAX_ITEMS) {
+        items->clear();
+        return false;
+    }
+    pairs->resize((items->size() + 1) / 2);
+    for (size_t k = 0; k < pairs->size(); ++k) {
+        CNode n;
+        std::memset(&n, 0, sizeof n);
+        put_box(n, 0, boxes[2 * k]);
+        put_box(n, 1, boxes[std::min(2 * k + 1, boxes.size() - 1)]);  // (an odd count: the last box twice, never a candidate)
+        ScanBoxes& out = (*pairs)[k];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 2; ++c) {
+                out.b[a][0][c] = out.b[a][2][c] = n.b[a][0][c];
+                out.b[a][1][c] = n.b[a][1][c];
+            }
+    }
+    return true;
+}
+
 // How far from the origin of the coordinates a ray may start and still be culled.
 //
 // Culling assumes that a hit the f64 shape tests accept lies on its shape up to a slack far below

@@ -101,6 +101,30 @@ struct alignas(8) ShapeRec {
 };
 static_assert(sizeof(ShapeRec) == 136, "ShapeRec is 136 bytes");
 
+// A scene of a handful of shapes is rendered without a tree (ScanWalk, device_traverse.h): every ray
+// is tested against the culling box of every ITEM, and exactly against the items whose box it
+// crosses.  An item is a sphere, a rect, or ONE FACE of a cube (hittable.rs:432-445 tests a cube as
+// six rects and keeps the closest, the later face on equal t -- which is what taking the faces as
+// items of their own, in that order, amounts to).  Items are numbered in the order (shape, face).
+//   f          sphere kinds: ShapeRec::f of the shape;  rect kinds: {a0, a1, b0, b1, k} as rect_hit takes them
+//   ref        bits 0..7 shape index | bits 8..10 TraverseKind of the exact test (a sphere kind or a rect kind)
+//              | bits 16.. what HitRec::side carries for a hit of this item: side | ShadeClass << 4 | TraverseKind
+//              of the SHAPE << 7
+constexpr uint32_t SCAN_MAX_ITEMS = 64;  // the items a ray has to test exactly are a 64-bit mask
+struct alignas(8) ScanItem {
+    double f[9];
+    uint32_t ref;
+    uint32_t pad;
+};
+static_assert(sizeof(ScanItem) == 80, "ScanItem is 80 bytes");
+// The culling boxes of items 2 i and 2 i + 1, as a CNode holds its two children's -- but with the lower
+// bounds a second time after the upper ones, so that near and far bound of an axis are read at
+// base + (ray runs down the axis ? 8 : 0) and 8 bytes behind it: one address per axis and ray.
+struct alignas(8) ScanBoxes {
+    float b[3][3][2];  // [axis][lower, upper, lower][item]
+};
+static_assert(sizeof(ScanBoxes) == 72, "ScanBoxes is 72 bytes");
+
 // Shade classes: paths are binned by this after each closest-hit query so that a
 // wave of the shade kernel runs one material/texture kind.
 enum ShadeClass : uint32_t {
@@ -144,7 +168,9 @@ struct DScene {
     // ... and rays that start farther than this from the origin of the coordinates (largest
     // component) are not culled either: see accel_build.h, cull_reach
     float cull_reach;
-    uint32_t pad_;
+    uint32_t n_scan_items;           // 0: the scene has too many shapes to be rendered without a tree
+    const ScanBoxes* scan_boxes;     // culling boxes of the items, two per entry
+    const ScanItem* scan_items;
 };
 
 }  // namespace mirt

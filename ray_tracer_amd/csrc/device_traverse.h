@@ -115,6 +115,8 @@ struct TraverseLds {
     const char* nodes;   // copies of the first n_top nodes of DScene::nodes (breadth-first: the top of the tree), NODE_LDS_BYTES apart
     const char* shapes;  // SHAPE_LDS_BYTES apart, or nullptr: read DScene::recs
     uint32_t n_top;      // NODES_IN_LDS kernels: all of them
+    const char* items = nullptr;  // ScanWalk: copies of DScene::scan_items (`nodes` then holds DScene::scan_nodes)
+    uint32_t n_items = 0;
 };
 
 // The culling slab test, f32, for the two children of a node at once.
@@ -535,15 +537,86 @@ struct RayWalk {
     }
 };
 
+#ifdef MIRT_PATHS_STATS
+// development build: wave clocks of the two parts of ScanWalk::leaf_step, trips of the second
+__device__ unsigned long long g_scan_stats[4];
+#endif
+// The exact test of one item of a scene that is rendered without a tree (ScanWalk below), each lane its
+// own item.  Rects of the three orientations share one piece of code: the axes are data.
+// (A free function over the ray's components BY VALUE: written as a member that reads them from the
+// walk, the selects between components become loads from a selected address, and the whole walk then
+// lives in scratch memory instead of registers.)
+// Is a ray sure to start on (within what t_min cuts off of) the rect-kind item at position k of its axis?
+// |k - o| < |d| t_min (1 - 1e-9) implies |t| < t_min for the rounded quotient t = (k - o) / d as well.
+__device__ __forceinline__ bool scan_starts_on(uint32_t kind, double k, double ox, double oy, double oz, double dx, double dy, double dz,
+                                               double t_min) {
+    const bool k_is_x = kind == TK_YZ_RECT, k_is_z = kind == TK_XY_RECT;
+    const bool rect = k_is_x || k_is_z || kind == TK_XZ_RECT;
+    const double ok = k_is_x ? ox : k_is_z ? oz : oy, dk = k_is_x ? dx : k_is_z ? dz : dy;
+    return rect && fabs(k - ok) < fabs(dk) * (t_min * (1.0 - 1.0e-9));
+}
+
+struct ItemHit {
+    bool hit;
+    double t;
+    uint32_t ref;  // ScanItem::ref
+};
+__device__ __forceinline__ ItemHit scan_item_test(uint32_t lds_items, uint32_t item, double ox, double oy, double oz, double dx, double dy,
+                                                  double dz, double time, double dd, double t_min, double t_max) {
+    const uint32_t rec = lds_items + item * (uint32_t)sizeof(ScanItem);
+    // the reference word and the five parameters every kind has, one wait
+    const uint2 ref_word = lds_read_u32x2<72>(rec);
+    const double f0 = lds_read_f64<0>(rec), f1 = lds_read_f64<8>(rec), f2 = lds_read_f64<16>(rec);
+    const double f3 = lds_read_f64<24>(rec), f4 = lds_read_f64<32>(rec);
+    lds_wait();
+    ItemHit out;
+    out.ref = ref_word.x;
+    out.t = 0.0;
+    const uint32_t kind = (out.ref >> 8) & 7u;
+    if (kind == TK_SPHERE || kind == TK_MOVING_SPHERE) {
+        double p[9] = {f0, f1, f2, f3, f4, 0.0, 0.0, 0.0, 0.0};
+        p[5] = lds_read_f64<40>(rec), p[6] = lds_read_f64<48>(rec), p[7] = lds_read_f64<56>(rec), p[8] = lds_read_f64<64>(rec);
+        lds_wait();
+        RayD r;
+        r.o = v3(ox, oy, oz);
+        r.d = v3(dx, dy, dz);
+        r.time = time;
+        int side;
+        out.hit = tshape_hit(p, kind, r, dd, t_min, t_max, &out.t, &side);
+    } else {
+        // rect_hit (device_intersect.h; hittable.rs:185-207, 249-271, 313-335): K = the axis the rect is
+        // perpendicular to, A / B = the other two in their order
+        const double a0 = f0, a1 = f1, b0 = f2, b1 = f3, k = f4;
+        const bool k_is_x = kind == TK_YZ_RECT, k_is_z = kind == TK_XY_RECT;
+        const double ok = k_is_x ? ox : k_is_z ? oz : oy, dk = k_is_x ? dx : k_is_z ? dz : dy;
+        const double oa = k_is_x ? oy : ox, da = k_is_x ? dy : dx;
+        const double ob = k_is_z ? oy : oz, db = k_is_z ? dy : dz;
+        const double t = (k - ok) / dk;
+        out.t = t;
+        out.hit = !(t < t_min || t > t_max);
+        if (out.hit) {
+            const double a = oa + t * da;
+            const double b = ob + t * db;
+            out.hit = !(a < a0 || a > a1 || b < b0 || b > b1);
+        }
+    }
+    return out;
+}
+
 // The same interface for a scene of a handful of shapes (the Cornell box has eight): no tree at all.
-// One "shape test" step tests EVERY shape, in index order, for all lanes that wait for it -- the loop
-// and the shape's kind are the same for the whole wave (scalar branches, the shape's parameters in
-// scalar registers, read through the constant address space: they are written before the launch and
-// never after), so the wave never splits over which shape or which kind of shape comes next.  Walking
-// a tree of eight shapes costs more in divergence than it saves in tests.
-// The closest hit among all shapes is then confirmed against the reference's boxes exactly as
-// RayWalk does it (confirm / begin_careful), which is why the culling constants are still prepared.
-template <int BLOCK, bool SHAPES_IN_LDS>
+// One "shape test" step does the whole query for all lanes that wait for it, in two parts:
+//   1. the culling box of EVERY item (device_scene.h, ScanItem: a sphere, a rect, one face of a cube) against
+//      the ray, two boxes at a time with the same f32 slab test as a node visit -- the loop is the same
+//      for the whole wave, no lane waits for another's walk;
+//   2. the exact test of the items whose box the ray crosses (one to three in a room of rects and
+//      cubes: a wall, the faces of a cube where the ray enters and leaves it), each lane its own next
+//      item per trip.  Rects of the three orientations share one piece of code (the axes are data),
+//      so the trips do not split by orientation.
+// Walking a tree of eight shapes costs more in divergence than it saves in tests, and testing all six
+// faces of every cube exactly costs six divisions where two faces can be hit at all.
+// The closest hit among all items is then confirmed against the reference's boxes exactly as
+// RayWalk does it (confirm / begin_careful).
+template <int BLOCK>
 struct ScanWalk {
     static constexpr uint32_t SIDE_MASK = 15u, CLASS_SHIFT = 4, TK_SHIFT = 7;
     static constexpr bool PACKED = false;
@@ -552,10 +625,20 @@ struct ScanWalk {
     HitRec best;
     bool pending;  // the scan of this ray is still to be done
     bool careful;  // second scan: a hit counts only if its shape's gates pass
+    static constexpr uint32_t NO_ITEM = 255u;
+    uint32_t from_item;  // the item the ray starts on (a scattered ray), or NO_ITEM
+#ifdef MIRT_PATHS_STATS
+    unsigned long long stat[4] = {};
+    __device__ __forceinline__ void flush_stats() {
+        for (int k = 0; k < 4; ++k)
+            if (stat[k]) atomicAdd(&g_scan_stats[k], stat[k]);
+    }
+#endif
 
     __device__ __forceinline__ void reset() {
         pending = false;
         careful = false;
+        from_item = NO_ITEM;
         best = HitRec{0.0, -1, 0};
     }
     __device__ __forceinline__ bool wants_node() const { return false; }
@@ -566,16 +649,19 @@ struct ScanWalk {
 
     __device__ __forceinline__ void begin(const DScene& sc, const RayD& ray, double t_min, double t_max) {
         r = ray;
-        // (the constants serve sure_to_cross only, which holds for any ray they are `tame` for)
-        cull.set(r, r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z);
+        // (when a ray may be culled at all: RayWalk::begin)
+        const float from = fmaxf(fmaxf(__builtin_fabsf((float)r.o.x), __builtin_fabsf((float)r.o.y)), __builtin_fabsf((float)r.o.z));
+        cull.set(r, r.time >= sc.time_lo && r.time <= sc.time_hi && from <= sc.cull_reach &&
+                        r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z);
         careful = false;
         pending = true;
+        // (a scattered ray: `best` still is the hit it starts from)
+        from_item = best.prim >= 0 ? (uint32_t)best.side >> 24 : NO_ITEM;
         best = HitRec{0.0, -1, 0};
     }
     __device__ __forceinline__ bool confirm(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
         if (careful || best.prim < 0) return true;
-        const ShapeRec* rec = SHAPES_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)best.prim * SHAPE_LDS_BYTES)
-                                            : sc.recs + best.prim;
+        const ShapeRec* rec = reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)best.prim * SHAPE_LDS_BYTES);
         if (cull.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) return true;
         return gates_pass(sc.gates, sc.gate_of, (uint32_t)best.prim, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max);
     }
@@ -587,28 +673,112 @@ struct ScanWalk {
     template <class StackT>
     __device__ __forceinline__ void node_step(const DScene&, const TraverseLds&, StackT*, uint32_t, double) {}
 
+    // The exact test of item `item` (each lane its own), and `best` if it wins.
+    __device__ __forceinline__ void exact_test(const DScene& sc, const TraverseLds& lds, uint32_t item, double dd, double t_min, double t_max) {
+        const ItemHit h = scan_item_test((uint32_t)(size_t)lds.items, item, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.time, dd, t_min, t_max);
+        // of equal t the later item wins (bvh.rs:70-74 between shapes, hittable.rs:432-445 between the
+        // faces of a cube); best.side carries the item's number above the bits a hit's side uses
+        const uint32_t index = h.ref & 255u;
+        if (h.hit && (best.prim < 0 || h.t < best.t || (h.t == best.t && item > ((uint32_t)best.side >> 24)))) {
+            if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max))
+                best = HitRec{h.t, (int32_t)index, (int32_t)((h.ref >> 16) | item << 24)};
+        }
+    }
+
     __device__ __forceinline__ void leaf_step(const DScene& sc, const TraverseLds& lds, double t_min, double t_max) {
-        typedef const __attribute__((address_space(4))) ShapeRec* ConstRecs;
-        typedef const __attribute__((address_space(4))) DShape* ConstShapes;
-        const ConstRecs recs = (ConstRecs)(uintptr_t)sc.recs;
-        const ConstShapes shapes = (ConstShapes)(uintptr_t)sc.shapes;
-        const uint32_t n = sc.n_shapes;
+#ifdef MIRT_PATHS_STATS
+        const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- 0. A ray that starts ON a rect (every scattered ray does) crosses that rect's box, which is as
+        // thick as f32 needs it, and the exact test then finds t = (k - o) / d below t_min.  That much is
+        // known without the division: |k - o| < |d| t_min (1 - 1e-9) implies |t| < t_min for the rounded
+        // quotient too.  Such an item is no candidate, or it would be "reached first" by every ray that
+        // leaves it.  (Other rects through the ray's origin -- the neighbouring face at a cube's edge --
+        // are rare and take the long way below.)
+        uint32_t skip = NO_ITEM;
+        if (from_item != NO_ITEM) {
+            const uint32_t rec = (uint32_t)(size_t)lds.items + from_item * (uint32_t)sizeof(ScanItem);
+            const uint2 ref_word = lds_read_u32x2<72>(rec);
+            const double k = lds_read_f64<32>(rec);
+            lds_wait();
+            skip = scan_starts_on((ref_word.x >> 8) & 7u, k, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min) ? from_item : NO_ITEM;
+        }
+        // ---- 1. which items can the ray hit at all, and which of them does it reach first?
+        // An item's entry parameter (slab_pair) is a lower bound of the t of any hit on it.  Entry and
+        // item number travel as one key: the bits of the entry (not negative), its lowest six replaced by
+        // the number -- which lowers the bound by less than f32 resolves at 2^-17 and orders as the entry does.
+        const float t_lo = f32_not_above(t_min), t_hi = f32_not_below(t_max);
+        const uint32_t n_items = lds.n_items, n_pairs = (n_items + 1) >> 1;
+        uint32_t first = 0xFFFFFFFFu, second = 0xFFFFFFFFu;  // the two smallest keys
+        uint32_t entry_bits = ~63u;
+        asm volatile("" : "+v"(entry_bits));  // (in a vector register: and-or in one instruction with the item number as its scalar operand)
+        // one address per axis: near bound there, far bound 8 bytes behind it (ScanBoxes)
+        uint32_t ax = (uint32_t)(size_t)lds.nodes + cull.off[0];
+        uint32_t ay = (uint32_t)(size_t)lds.nodes + cull.off[1] + 24u;
+        uint32_t az = (uint32_t)(size_t)lds.nodes + cull.off[2] + 48u;
+        for (uint32_t pair = 0; pair < n_pairs; ++pair) {
+            const f32x2 nx = lds_read_f32x2<0>(ax), fx = lds_read_f32x2<8>(ax);
+            const f32x2 ny = lds_read_f32x2<0>(ay), fy = lds_read_f32x2<8>(ay);
+            const f32x2 nz = lds_read_f32x2<0>(az), fz = lds_read_f32x2<8>(az);
+            lds_wait();
+            ax += (uint32_t)sizeof(ScanBoxes), ay += (uint32_t)sizeof(ScanBoxes), az += (uint32_t)sizeof(ScanBoxes);
+            float e0, e1;
+            bool pass0, pass1;
+            slab_pair(nx, fx, ny, fy, nz, fz, cull, t_lo, t_hi, &e0, &e1, &pass0, &pass1);
+            const uint32_t item0 = 2u * pair, item1 = 2u * pair + 1u;
+            pass0 = pass0 && skip != item0;
+            pass1 = pass1 && skip != item1 && item1 < n_items;  // (an odd count: the last box is there twice)
+            // (a NaN entry -- nothing constrains the ray -- becomes 0, "before everything": the maximum of a NaN
+            // and a number is the number; slab_pair's results come out of max3 and need no quieting first)
+            asm("v_max_f32 %0, 0, %0" : "+v"(e0));
+            asm("v_max_f32 %0, 0, %0" : "+v"(e1));
+            const uint32_t key0 = pass0 ? (__float_as_uint(e0) & entry_bits) | item0 : 0xFFFFFFFFu;
+            const uint32_t key1 = pass1 ? (__float_as_uint(e1) & entry_bits) | item1 : 0xFFFFFFFFu;
+            second = max(min(first, second), min(max(first, second), key0));  // the median: second smallest of the three
+            first = min(first, key0);
+            second = max(min(first, second), min(max(first, second), key1));
+            first = min(first, key1);
+        }
+        const uint32_t first_item = first & 63u;
+        const float second_entry = __uint_as_float(second & ~63u);
+        // ---- 2. the exact test of the item reached first: a hit there that lies before every other item's
+        // entry is the closest hit (and so is none at all when no box is crossed)
         const double dd = dot(r.d, r.d);
-        for (uint32_t index = 0; index < n; ++index) {
-            double p[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) p[k] = recs[index].f[k];
-            const uint32_t tk = shapes[index].tk, cls = shapes[index].cls;
-            double t;
-            int side;
-            if (tshape_hit(p, tk, r, dd, t_min, t_max, &t, &side)) {
-                // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74) -- the later one here
-                if (best.prim < 0 || t <= best.t) {
-                    if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max))
-                        best = HitRec{t, (int32_t)index, (int32_t)((uint32_t)side | (cls | tk << 3) << CLASS_SHIFT)};
-                }
+#ifdef MIRT_PATHS_STATS
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
+        unsigned long long trips = 0;
+#endif
+        bool settled = first == 0xFFFFFFFFu;
+        if (!settled) {
+#ifdef MIRT_PATHS_STATS
+            trips += mbcnt_lt(__builtin_amdgcn_ballot_w64(true)) == 0 ? 1 : 0;
+#endif
+            exact_test(sc, lds, first_item, dd, t_min, t_max);
+            settled = second == 0xFFFFFFFFu || (best.prim >= 0 && best.t < (double)second_entry);
+        }
+        // ---- 3. otherwise (the box was crossed and the item missed, or two items lie within rounding of each
+        // other; a small share of the rays) the long way: the exact test of every item, in order
+        if (!settled) {
+            best = HitRec{0.0, -1, 0};
+            for (uint32_t item = 0; item < n_items; ++item) {
+#ifdef MIRT_PATHS_STATS
+                trips += mbcnt_lt(__builtin_amdgcn_ballot_w64(true)) == 0 ? 1 : 0;
+#endif
+                exact_test(sc, lds, item, dd, t_min, t_max);
             }
         }
+#ifdef MIRT_PATHS_STATS
+        {
+            const unsigned long long clk2 = __builtin_amdgcn_s_memtime();
+            const bool leader = mbcnt_lt(__builtin_amdgcn_ballot_w64(true)) == 0;
+            if (leader) {
+                stat[0] += clk1 - clk0;
+                stat[1] += clk2 - clk1;
+                stat[3] += 1ull;
+            }
+            stat[2] += trips;
+        }
+#endif
         pending = false;
     }
 };

@@ -169,6 +169,9 @@ __host__ __device__ inline size_t trav_stack_bytes(uint32_t levels, size_t entry
 __host__ __device__ inline size_t trav_nodes_bytes(uint32_t n_nodes) {
     return (((size_t)n_nodes * NODE_LDS_BYTES) + 15) & ~(size_t)15;
 }
+__host__ __device__ inline size_t scan_boxes_bytes(uint32_t n_pairs) {
+    return (((size_t)n_pairs * sizeof(ScanBoxes)) + 15) & ~(size_t)15;
+}
 
 // Copies the tree's nodes and the shapes' traversal parameters into LDS (whole workgroup).
 // REF16: leaf references in the copy become REF_LEAF | ref16_of(reference) (RayWalk::PACKED).
@@ -650,7 +653,8 @@ constexpr uint32_t PATHS_TUNING_BIG_TREE = 3u | (44u << 8) | (8u << 16) | (1u <<
 // no tree (ScanWalk): after a scan every lane is ready for shading, so shading never waits; the refill
 // threshold is what there is to choose
 constexpr uint32_t PATHS_TUNING_SCAN = 1u | (1u << 8) | (16u << 16) | (3u << 30);
-// Most shapes a scene may have to be rendered without a tree.
+// Most shapes a scene may have to be rendered without a tree (and at most SCAN_MAX_ITEMS items, a cube
+// counting six).
 #ifndef MIRT_SCAN_MAX_SHAPES
 #define MIRT_SCAN_MAX_SHAPES 16
 #endif
@@ -719,12 +723,22 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     }
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
-    char* lds_shapes = lds_nodes + trav_nodes_bytes(n_top);
+    char* lds_shapes = lds_nodes + (TREE == TREE_SCAN ? scan_boxes_bytes(n_top) : trav_nodes_bytes(n_top));
     typedef RayWalk<PATHS_BLOCK, StackT, NODES_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : MIRT_PARK_BIG> TreeWalk;
-    typedef typename std::conditional<SCAN, ScanWalk<PATHS_BLOCK, true>, TreeWalk>::type Walk;
+    typedef typename std::conditional<SCAN, ScanWalk<PATHS_BLOCK>, TreeWalk>::type Walk;
     static_assert(!Walk::PACKED || TREE_IN_LDS, "16-bit parked references need the at most 1 024 shapes of a tree that is in LDS as a whole");
+    // SCAN: n_top = the pairs of item boxes (DScene::scan_boxes), the items follow the shapes' records
+    char* lds_items = lds_shapes + (((size_t)sc.n_shapes * SHAPE_LDS_BYTES + 15) & ~(size_t)15);
+    if (SCAN) {
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.scan_boxes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
+        for (uint32_t w = threadIdx.x; w < n_top * (uint32_t)(sizeof(ScanBoxes) / 4); w += PATHS_BLOCK) dst[w] = src[w];
+        src = reinterpret_cast<const uint32_t*>(sc.scan_items);
+        dst = reinterpret_cast<uint32_t*>(lds_items);
+        for (uint32_t w = threadIdx.x; w < sc.n_scan_items * (uint32_t)(sizeof(ScanItem) / 4); w += PATHS_BLOCK) dst[w] = src[w];
+    }
     stage_tree<PATHS_BLOCK, !SCAN, RECS_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
-    const TraverseLds lds{lds_nodes, lds_shapes, n_top};
+    const TraverseLds lds{lds_nodes, lds_shapes, n_top, SCAN ? lds_items : nullptr, SCAN ? sc.n_scan_items : 0u};
 
     const Counters C{rp.max_depth};
     const uint32_t n = bounce0 == 0 ? rp.n_paths : P.counters[C.live(bounce0)];
@@ -923,6 +937,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
         atomicAdd(P.segments + 1, (unsigned long long)extra_segments);
     }
 #ifdef MIRT_PATHS_STATS
+    if constexpr (SCAN) walk.flush_stats();
     if (lane == 0) {
         for (int k = 0; k < PS_N; ++k) {
             atomicAdd(P.segments + 2 + 3 * k, ps_clk[k]);

@@ -365,6 +365,9 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
             return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", deepest, MAX_TREE_HEIGHT);
     }
     if (desc->nodes) sure_boxes(tree, &recs);
+    std::vector<ScanBoxes> scan_boxes;
+    std::vector<ScanItem> scan_items;
+    if (desc->nodes && desc->n_shapes <= 4 * MIRT_SCAN_MAX_SHAPES) build_scan_items(desc, recs, ref_bits.data(), &scan_boxes, &scan_items);
     const std::vector<CNode>& nodes = tree.nodes;
     const uint32_t root_ref = tree.root_ref, height = tree.height;
 
@@ -414,6 +417,10 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
     SCENE_TRY(upload(&d_recs, recs.data(), recs.size()));
     SCENE_TRY(upload(&d_shade_textures, shade_textures.data(), shade_textures.size()));
     SCENE_TRY(upload(&d_nodes, nodes.data(), nodes.size()));
+    ScanBoxes* d_scan_boxes = nullptr;
+    ScanItem* d_scan_items = nullptr;
+    SCENE_TRY(upload(&d_scan_boxes, scan_boxes.data(), scan_boxes.size()));
+    SCENE_TRY(upload(&d_scan_items, scan_items.data(), scan_items.size()));
     SCENE_TRY(upload(&d_gates, tree.gates.data(), tree.gates.size()));
     SCENE_TRY(upload(&d_gate_of, tree.gate_of.data(), tree.gate_of.size()));
     SCENE_TRY(upload(&d_members, desc->nodes, desc->nodes ? desc->n_nodes : 0));
@@ -435,6 +442,9 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
     sc->d.shade_textures = d_shade_textures;
     sc->d.n_shade_textures = (uint32_t)shade_textures.size();
     sc->d.nodes = d_nodes;
+    sc->d.scan_boxes = d_scan_boxes;
+    sc->d.scan_items = d_scan_items;
+    sc->d.n_scan_items = (uint32_t)scan_items.size();
     sc->d.gates = d_gates;
     sc->d.gate_of = d_gate_of;
     sc->d.time_lo = tree.time_lo;
@@ -812,12 +822,12 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
         const char* s = std::getenv("MIRT_SCAN_MAX");
         return s ? (uint32_t)std::strtoul(s, nullptr, 0) : (uint32_t)MIRT_SCAN_MAX_SHAPES;
     }();
-    if (scene->d.n_shapes <= scan_max) {
+    if (scene->d.n_scan_items && scene->d.n_shapes <= scan_max) {
         p.scan = true;
         p.tree_in_lds = false;
         p.levels = 0;
-        p.n_top = 0;
-        p.lds_bytes = recs;
+        p.n_top = (scene->d.n_scan_items + 1) / 2;
+        p.lds_bytes = scan_boxes_bytes(p.n_top) + ((recs + 15) & ~(size_t)15) + (size_t)scene->d.n_scan_items * sizeof(ScanItem);
         p.kernel = paths_kernel_for<uint16_t, TREE_SCAN>(textures);
     } else if (p.tree_in_lds) {
         p.n_top = scene->d.n_nodes;
@@ -1148,6 +1158,10 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         const char* parts[8] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "next ray / store"};
         for (int k = 0; k < 8; ++k)
             std::fprintf(stderr, "[k_paths]   shade: %-20s %5.1f %% of wave clocks\n", parts[k], 100.0 * (double)segments[2 + 13 + k] / total);
+        unsigned long long scan[4] = {};
+        if (hipMemcpyFromSymbol(scan, HIP_SYMBOL(g_scan_stats), sizeof scan) == hipSuccess && scan[3])
+            std::fprintf(stderr, "[k_paths]   scan: %.0f clocks for the boxes, %.0f for the exact tests, %.2f trips of exact tests per scan\n",
+                         (double)scan[0] / scan[3], (double)scan[1] / scan[3], (double)scan[2] / scan[3]);
     }
 #endif
 
