@@ -101,22 +101,22 @@ struct alignas(8) ShapeRec {
 };
 static_assert(sizeof(ShapeRec) == 136, "ShapeRec is 136 bytes");
 
-// A scene of a handful of shapes is rendered without a tree (ScanWalk, device_traverse.h): every ray
-// is tested against the culling box of every ITEM, and exactly against the items whose box it
-// crosses.  An item is a sphere, a rect, or ONE FACE of a cube (hittable.rs:432-445 tests a cube as
+// A scene of a handful of rects and cubes (the Cornell box) is rendered without a tree (ScanWalk,
+// device_traverse.h): every ray is tested against the culling box of every ITEM, and exactly against the
+// item it reaches first.  An item is a rect or ONE FACE of a cube (hittable.rs:432-445 tests a cube as
 // six rects and keeps the closest, the later face on equal t -- which is what taking the faces as
 // items of their own, in that order, amounts to).  Items are numbered in the order (shape, face).
-//   f          sphere kinds: ShapeRec::f of the shape;  rect kinds: {a0, a1, b0, b1, k} as rect_hit takes them
-//   ref        bits 0..7 shape index | bits 8..10 TraverseKind of the exact test (a sphere kind or a rect kind)
+//   f          {a0, a1, b0, b1, k} as rect_hit takes them
+//   ref        bits 0..7 shape index | bits 8..10 TraverseKind of the rect (its orientation)
 //              | bits 16.. what HitRec::side carries for a hit of this item: side | ShadeClass << 4 | TraverseKind
 //              of the SHAPE << 7
 constexpr uint32_t SCAN_MAX_ITEMS = 64;  // the items a ray has to test exactly are a 64-bit mask
 struct alignas(8) ScanItem {
-    double f[9];
+    double f[5];
     uint32_t ref;
     uint32_t pad;
 };
-static_assert(sizeof(ScanItem) == 80, "ScanItem is 80 bytes");
+static_assert(sizeof(ScanItem) == 48, "ScanItem is 48 bytes");
 // The culling boxes of items 2 i and 2 i + 1, as a CNode holds its two children's -- but with the lower
 // bounds a second time after the upper ones, so that near and far bound of an axis are read at
 // base + (ray runs down the axis ? 8 : 0) and 8 bytes behind it: one address per axis and ray.

@@ -541,8 +541,8 @@ struct RayWalk {
 // development build: wave clocks of the two parts of ScanWalk::leaf_step, trips of the second
 __device__ unsigned long long g_scan_stats[4];
 #endif
-// The exact test of one item of a scene that is rendered without a tree (ScanWalk below), each lane its
-// own item.  Rects of the three orientations share one piece of code: the axes are data.
+// The exact test of one item (a rect, or one face of a cube) of a scene that is rendered without a tree
+// (ScanWalk below), each lane its own item.  The three orientations share one piece of code: the axes are data.
 // (A free function over the ray's components BY VALUE: written as a member that reads them from the
 // walk, the selects between components become loads from a selected address, and the whole walk then
 // lives in scratch memory instead of registers.)
@@ -562,58 +562,46 @@ struct ItemHit {
     uint32_t ref;  // ScanItem::ref
 };
 __device__ __forceinline__ ItemHit scan_item_test(uint32_t lds_items, uint32_t item, double ox, double oy, double oz, double dx, double dy,
-                                                  double dz, double time, double dd, double t_min, double t_max) {
+                                                  double dz, double t_min, double t_max) {
     const uint32_t rec = lds_items + item * (uint32_t)sizeof(ScanItem);
-    // the reference word and the five parameters every kind has, one wait
-    const uint2 ref_word = lds_read_u32x2<72>(rec);
-    const double f0 = lds_read_f64<0>(rec), f1 = lds_read_f64<8>(rec), f2 = lds_read_f64<16>(rec);
-    const double f3 = lds_read_f64<24>(rec), f4 = lds_read_f64<32>(rec);
+    const uint2 ref_word = lds_read_u32x2<40>(rec);
+    const double a0 = lds_read_f64<0>(rec), a1 = lds_read_f64<8>(rec), b0 = lds_read_f64<16>(rec);
+    const double b1 = lds_read_f64<24>(rec), k = lds_read_f64<32>(rec);
     lds_wait();
     ItemHit out;
     out.ref = ref_word.x;
-    out.t = 0.0;
+    // rect_hit (device_intersect.h; hittable.rs:185-207, 249-271, 313-335): K = the axis the rect is
+    // perpendicular to, A / B = the other two in their order
     const uint32_t kind = (out.ref >> 8) & 7u;
-    if (kind == TK_SPHERE || kind == TK_MOVING_SPHERE) {
-        double p[9] = {f0, f1, f2, f3, f4, 0.0, 0.0, 0.0, 0.0};
-        p[5] = lds_read_f64<40>(rec), p[6] = lds_read_f64<48>(rec), p[7] = lds_read_f64<56>(rec), p[8] = lds_read_f64<64>(rec);
-        lds_wait();
-        RayD r;
-        r.o = v3(ox, oy, oz);
-        r.d = v3(dx, dy, dz);
-        r.time = time;
-        int side;
-        out.hit = tshape_hit(p, kind, r, dd, t_min, t_max, &out.t, &side);
-    } else {
-        // rect_hit (device_intersect.h; hittable.rs:185-207, 249-271, 313-335): K = the axis the rect is
-        // perpendicular to, A / B = the other two in their order
-        const double a0 = f0, a1 = f1, b0 = f2, b1 = f3, k = f4;
-        const bool k_is_x = kind == TK_YZ_RECT, k_is_z = kind == TK_XY_RECT;
-        const double ok = k_is_x ? ox : k_is_z ? oz : oy, dk = k_is_x ? dx : k_is_z ? dz : dy;
-        const double oa = k_is_x ? oy : ox, da = k_is_x ? dy : dx;
-        const double ob = k_is_z ? oy : oz, db = k_is_z ? dy : dz;
-        const double t = (k - ok) / dk;
-        out.t = t;
-        out.hit = !(t < t_min || t > t_max);
-        if (out.hit) {
-            const double a = oa + t * da;
-            const double b = ob + t * db;
-            out.hit = !(a < a0 || a > a1 || b < b0 || b > b1);
-        }
+    const bool k_is_x = kind == TK_YZ_RECT, k_is_z = kind == TK_XY_RECT;
+    const double ok = k_is_x ? ox : k_is_z ? oz : oy, dk = k_is_x ? dx : k_is_z ? dz : dy;
+    const double oa = k_is_x ? oy : ox, da = k_is_x ? dy : dx;
+    const double ob = k_is_z ? oy : oz, db = k_is_z ? dy : dz;
+    const double t = (k - ok) / dk;
+    out.t = t;
+    out.hit = !(t < t_min || t > t_max);
+    if (out.hit) {
+        const double a = oa + t * da;
+        const double b = ob + t * db;
+        out.hit = !(a < a0 || a > a1 || b < b0 || b > b1);
     }
     return out;
 }
 
-// The same interface for a scene of a handful of shapes (the Cornell box has eight): no tree at all.
-// One "shape test" step does the whole query for all lanes that wait for it, in two parts:
-//   1. the culling box of EVERY item (device_scene.h, ScanItem: a sphere, a rect, one face of a cube) against
-//      the ray, two boxes at a time with the same f32 slab test as a node visit -- the loop is the same
-//      for the whole wave, no lane waits for another's walk;
-//   2. the exact test of the items whose box the ray crosses (one to three in a room of rects and
-//      cubes: a wall, the faces of a cube where the ray enters and leaves it), each lane its own next
-//      item per trip.  Rects of the three orientations share one piece of code (the axes are data),
-//      so the trips do not split by orientation.
+// The same interface for a scene of a handful of rects and cubes (the Cornell box has eight shapes): no
+// tree at all.  One "shape test" step does the whole query for all lanes that wait for it:
+//   1. the culling box of EVERY item (device_scene.h, ScanItem: a rect, or one face of a cube) against the
+//      ray, two boxes at a time with the same f32 slab test as a node visit -- the loop is the same for
+//      the whole wave, no lane waits for another's walk -- keeping the two smallest entry parameters;
+//   2. the exact test of the item reached first, each lane its own.  A rect's box is the rect, as thick
+//      as f32 needs it, so the ray nearly always hits that item, and a hit that lies before the entry
+//      of every other item is the closest hit.  Rects of the three orientations share one piece of
+//      code (the axes are data), so the trip does not split by orientation;
+//   3. for the rays that step 2 did not settle (a small share), the exact test of every item.
 // Walking a tree of eight shapes costs more in divergence than it saves in tests, and testing all six
-// faces of every cube exactly costs six divisions where two faces can be hit at all.
+// faces of a cube exactly costs six divisions where two faces can be hit at all.  (Spheres are left to
+// the tree: a ray that crosses a sphere's box misses the sphere one time in four, so step 2 settles
+// too little; measured slower than the tree from four spheres on.)
 // The closest hit among all items is then confirmed against the reference's boxes exactly as
 // RayWalk does it (confirm / begin_careful).
 template <int BLOCK>
@@ -674,8 +662,8 @@ struct ScanWalk {
     __device__ __forceinline__ void node_step(const DScene&, const TraverseLds&, StackT*, uint32_t, double) {}
 
     // The exact test of item `item` (each lane its own), and `best` if it wins.
-    __device__ __forceinline__ void exact_test(const DScene& sc, const TraverseLds& lds, uint32_t item, double dd, double t_min, double t_max) {
-        const ItemHit h = scan_item_test((uint32_t)(size_t)lds.items, item, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.time, dd, t_min, t_max);
+    __device__ __forceinline__ void exact_test(const DScene& sc, const TraverseLds& lds, uint32_t item, double t_min, double t_max) {
+        const ItemHit h = scan_item_test((uint32_t)(size_t)lds.items, item, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max);
         // of equal t the later item wins (bvh.rs:70-74 between shapes, hittable.rs:432-445 between the
         // faces of a cube); best.side carries the item's number above the bits a hit's side uses
         const uint32_t index = h.ref & 255u;
@@ -698,7 +686,7 @@ struct ScanWalk {
         uint32_t skip = NO_ITEM;
         if (from_item != NO_ITEM) {
             const uint32_t rec = (uint32_t)(size_t)lds.items + from_item * (uint32_t)sizeof(ScanItem);
-            const uint2 ref_word = lds_read_u32x2<72>(rec);
+            const uint2 ref_word = lds_read_u32x2<40>(rec);
             const double k = lds_read_f64<32>(rec);
             lds_wait();
             skip = scan_starts_on((ref_word.x >> 8) & 7u, k, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min) ? from_item : NO_ITEM;
@@ -743,7 +731,6 @@ struct ScanWalk {
         const float second_entry = __uint_as_float(second & ~63u);
         // ---- 2. the exact test of the item reached first: a hit there that lies before every other item's
         // entry is the closest hit (and so is none at all when no box is crossed)
-        const double dd = dot(r.d, r.d);
 #ifdef MIRT_PATHS_STATS
         const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
         unsigned long long trips = 0;
@@ -753,7 +740,7 @@ struct ScanWalk {
 #ifdef MIRT_PATHS_STATS
             trips += mbcnt_lt(__builtin_amdgcn_ballot_w64(true)) == 0 ? 1 : 0;
 #endif
-            exact_test(sc, lds, first_item, dd, t_min, t_max);
+            exact_test(sc, lds, first_item, t_min, t_max);
             settled = second == 0xFFFFFFFFu || (best.prim >= 0 && best.t < (double)second_entry);
         }
         // ---- 3. otherwise (the box was crossed and the item missed, or two items lie within rounding of each
@@ -764,7 +751,7 @@ struct ScanWalk {
 #ifdef MIRT_PATHS_STATS
                 trips += mbcnt_lt(__builtin_amdgcn_ballot_w64(true)) == 0 ? 1 : 0;
 #endif
-                exact_test(sc, lds, item, dd, t_min, t_max);
+                exact_test(sc, lds, item, t_min, t_max);
             }
         }
 #ifdef MIRT_PATHS_STATS

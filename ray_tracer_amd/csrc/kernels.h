@@ -653,8 +653,8 @@ constexpr uint32_t PATHS_TUNING_BIG_TREE = 3u | (44u << 8) | (8u << 16) | (1u <<
 // no tree (ScanWalk): after a scan every lane is ready for shading, so shading never waits; the refill
 // threshold is what there is to choose
 constexpr uint32_t PATHS_TUNING_SCAN = 1u | (1u << 8) | (16u << 16) | (3u << 30);
-// Most shapes a scene may have to be rendered without a tree (and at most SCAN_MAX_ITEMS items, a cube
-// counting six).
+// Most shapes a scene of rects and cubes may have to be rendered without a tree (and at most SCAN_MAX_ITEMS
+// items, a cube counting six).
 #ifndef MIRT_SCAN_MAX_SHAPES
 #define MIRT_SCAN_MAX_SHAPES 16
 #endif
@@ -692,7 +692,7 @@ enum : int {
     TREE_GLOBAL = 0,     // both from global memory
     TREE_LDS = 1,        // both staged in LDS
     TREE_NODES_LDS = 2,  // the nodes in LDS, the records (2.4 times their size) from global memory
-    TREE_SCAN = 3        // a handful of shapes: no tree, every ray is tested against every shape (ScanWalk)
+    TREE_SCAN = 3        // a handful of rects and cubes: no tree, every ray against the box of every rect and face (ScanWalk)
 };
 template <class StackT, int TEXTURES, int TREE>
 __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(

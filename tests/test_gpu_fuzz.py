@@ -24,8 +24,8 @@ def _perlin(seed):
     return p
 
 
-def _random_world(seed, n_shapes=(24, 90)):
-    rng = np.random.default_rng(1000 + seed + 7919 * n_shapes[0])
+def _random_world(seed, n_shapes=(24, 90), planar=False):
+    rng = np.random.default_rng(1000 + seed + 7919 * n_shapes[0] + (104729 if planar else 0))
     image = rng.integers(0, 256, (9, 14, 3), dtype=np.uint8)
     n_const = 6
     textures = [su.constant(*rng.uniform(0.05, 0.95, 3)) for _ in range(n_const)]
@@ -49,7 +49,7 @@ def _random_world(seed, n_shapes=(24, 90)):
     for k in range(n):
         c = rng.uniform(-6.0, 6.0, 3)
         m = int(rng.integers(0, len(materials)))
-        kind = int(rng.integers(0, 7))
+        kind = int(rng.integers(4, 7)) if planar else int(rng.integers(0, 7))
         if kind == 0:
             shapes.append(su.moving_sphere(c, c + rng.uniform(-0.8, 0.8, 3), rng.uniform(0.3, 1.4), 0.0, 1.0, m))
         elif kind == 1:
@@ -61,7 +61,10 @@ def _random_world(seed, n_shapes=(24, 90)):
         else:
             a = rng.uniform(0.8, 5.0, 2)
             shapes.append(su.shape(abi.SHAPE_XY_RECT + int(rng.integers(0, 3)), m, c[0], c[0] + a[0], c[1], c[1] + a[1], c[2]))
-    shapes.append(su.sphere(0.0, -1006.5, 0.0, 1000.0, int(rng.integers(0, len(textures)))))  # ground
+    if planar:
+        shapes.append(su.shape(abi.SHAPE_XZ_RECT, int(rng.integers(0, len(textures))), -40.0, 40.0, -40.0, 40.0, -6.5))  # ground
+    else:
+        shapes.append(su.sphere(0.0, -1006.5, 0.0, 1000.0, int(rng.integers(0, len(textures)))))  # ground
     built = su.Built(shapes, materials, textures, perlins=[_perlin(77 + seed)], images=[image], seed=seed)
     eye = rng.uniform(-1.0, 1.0, 3)
     eye = eye / np.linalg.norm(eye) * rng.uniform(9.0, 16.0)
@@ -71,10 +74,11 @@ def _random_world(seed, n_shapes=(24, 90)):
     return built, eye, aperture, shutter
 
 
-@pytest.mark.parametrize("seed,n_shapes", [(s, (24, 90)) for s in range(10)] + [(s, (1 + s % 5, 16)) for s in range(12)])
-def test_random_worlds_render_and_intersect_like_the_oracle(seed, n_shapes, oracle):
-    """(worlds of at most 16 shapes are rendered without a tree: every shape tested for every ray)"""
-    built, eye, aperture, shutter = _random_world(seed, n_shapes)
+@pytest.mark.parametrize("seed,n_shapes,planar", [(s, (24, 90), False) for s in range(10)] + [(s, (1 + s % 5, 16), False) for s in range(8)] +
+                         [(s, (1 + s % 4, 11), True) for s in range(10)])
+def test_random_worlds_render_and_intersect_like_the_oracle(seed, n_shapes, planar, oracle):
+    """(planar: rects and cubes only -- such a world, when small, is rendered without a tree, cube faces as items of their own)"""
+    built, eye, aperture, shutter = _random_world(seed, n_shapes, planar)
     w, h, spp = 72, 48, 4
     cam = api.Camera.new(tuple(eye), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, w / h, aperture, float(np.linalg.norm(eye)), *shutter)
     background = (api.SKY, api.BLACK)[seed % 2] if n_shapes[0] >= 24 else api.SKY
