@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--split", default=None, choices=["tile", "sample"],
-                    help="how N > 1 GPUs share the frame; default: tile, and sample for C5 (as BASELINE.json names them)")
+                    help="how N > 1 GPUs share the frame; default: tile, and sample for C5 (the split each configuration is specified with)")
     ap.add_argument("--paths-per-pass", type=int, default=0)
     ap.add_argument("--handover", type=int, default=0,
                     help="mirt_render_opts.handover_bounce: 0 = path kernel from the camera ray (default), N = launches per "
