@@ -4,7 +4,7 @@ samples per pixel -- through the fast and the reference-order traversal: hit / m
 cube side and t bit for bit.  (The f32 culling margins of the fast traversal are the kind of
 thing that fails once in 10^8 rays, not once in 10^4.)  And whole frames at the benchmark's own
 sizes, one sample per pixel: the path kernel against the launch-per-bounce pipeline, byte for
-byte and query for query."""
+byte and query for query; and frames of tens of millions of paths against the oracle's image."""
 import numpy as np
 import pytest
 
@@ -55,6 +55,26 @@ def test_full_size_frames_path_kernel_against_pipeline(name, worlds):
         assert paths.std() > 5  # an image
     finally:
         scene.close()
+
+
+# frames of (nearly) the benchmark's own sizes, a few samples per pixel: 12 to 34 million paths per scene
+RENDER_FRAMES = {"C2": (1200, 800, 16), "C3": (1920, 1080, 8), "C4": (1024, 1024, 32), "C5": (1920, 1080, 6)}
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5"])
+def test_tens_of_millions_of_paths_render_the_oracle_bytes(name, worlds, oracle):
+    """The path kernel against the oracle with the same sampler: as many closest-hit queries, and
+    the image byte for byte (renderer.rs:64-116 end to end; the oracle runs on all host cores)."""
+    cfg = configs.ALL[name]
+    w, h, spp = RENDER_FRAMES[name]
+    world = worlds(name)
+    cam = cfg.camera(w, h)
+    ref, _, ctr, _ = oracle.render(world.desc, cam, cfg.background, w, h, spp)
+    gpu, st = api.render_world(cfg.background, world, cam, w, h, spp, return_stats=True)
+    assert st["samples"] == w * h * spp >= 12_000_000
+    assert st["segments"] == ctr["segments"], f"{name}: {st['segments']} queries, the oracle made {ctr['segments']}"
+    diff = np.abs(gpu.astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-5 * diff.size, f"{name}: {np.count_nonzero(diff)} bytes differ, by up to {diff.max()}"
 
 
 @pytest.mark.parametrize("n", [1_500, 3_000, 70_000])
