@@ -172,6 +172,10 @@ def main():
         raise SystemExit(f"--split sample needs at least one sample per rank: spp {spp} < {n_ranks} ranks")
     world = cfg.world()
     cam = cfg.camera()
+    # the first call into the library pays for the HIP context and for loading its code object, once per process
+    t_upload = time.perf_counter()
+    api.Scene(world, device=device_index).close()
+    first_call_ms = (time.perf_counter() - t_upload) * 1e3
     t_upload = time.perf_counter()
     scene = api.Scene(world, device=device_index)  # scene resident in HBM before the timed region
     scene_upload_ms = (time.perf_counter() - t_upload) * 1e3  # culling-tree build on the host + copies; outside `value`
@@ -277,6 +281,7 @@ def main():
             "handover": {"bounce": int(step_stats[-1]["handover_bounce"]),
                          "path_kernel_segments_frac": tot["segments_paths"] / max(1.0, tot["segments"])},
             "scene_upload_ms": scene_upload_ms,
+            "library_first_call_ms": first_call_ms,
             "mrays_per_s": tot["segments"] / elapsed / 1e6,
             "segments_per_sample": tot["segments"] / samples,
         }
