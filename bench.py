@@ -137,6 +137,11 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     elif world_size != args.gpus:
         args.gpus = world_size
+    # ONE line on stdout, the result: whatever else the libraries below write there (gloo announces its
+    # connections on stdout) goes to stderr instead, in every rank
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -369,7 +374,7 @@ def main():
                     "note": "reference-traversal op count of this kernel's rays (shading not counted) / its time",
                 }
                 result["roofline"]["valu_f64"]["frac"] = result["roofline"]["valu_f64"]["achieved_tops"] / FP64_VALU_PEAK_TOPS
-        print(json.dumps(result))
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
 
     for sc in set(rank_scenes):
         sc.close()
