@@ -466,10 +466,26 @@ struct RayWalk {
             slab_pair(nx, fx, ny, fy, nz, fz, cull, t_lo, t_hi, &e0, &e1, &pass0, &pass1);
         }
         const bool leaf0 = (c0 & REF_LEAF) != 0, leaf1 = (c1 & REF_LEAF) != 0;
-        if (pass0 && leaf0) park(c0);
-        if (pass1 && leaf1) park(c1);
-        const bool go0 = pass0 && !leaf0;
-        const bool go1 = pass1 && !leaf1;
+        // (the same decisions written two ways: how the compiler lays out the compares and branches is worth
+        // +1.2 % on the RTIOW scene for the first form with the tree in LDS, and -0.9 % on the 3,500-shape scene,
+        // whose nodes come from global memory)
+        bool go0, go1;
+        if (NODES_IN_LDS) {
+            go0 = go1 = false;
+            if (pass0) {
+                if (leaf0) park(c0);
+                else go0 = true;
+            }
+            if (pass1) {
+                if (leaf1) park(c1);
+                else go1 = true;
+            }
+        } else {
+            if (pass0 && leaf0) park(c0);
+            if (pass1 && leaf1) park(c1);
+            go0 = pass0 && !leaf0;
+            go1 = pass1 && !leaf1;
+        }
         if (go0 && go1) {
             const bool first0 = e0 <= e1;
             stack[sp * BLOCK + tid] = (StackT)(first0 ? c1 : c0);
