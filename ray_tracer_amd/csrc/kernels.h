@@ -642,10 +642,12 @@ __host__ __device__ constexpr int paths_block(int textures) { return 256 * paths
 //   bit 31      such walks are finished off by the refill (the lane counts as empty)
 // Measured at 64 samples per pixel, relative to 3 | 48 << 8 | 16 << 16 | 1 << 30: bit 31 gives +12 % on
 // the textured scene (tree in LDS), -1 % on the Cornell box, -4 % on the 3,500-shape scene; a refill at
-// 24 empty lanes instead of 16 another +2.5 % on RTIOW and -2.5 % on the Cornell box.
+// 24 empty lanes instead of 16 another +2.5 % on RTIOW and -2.5 % on the Cornell box (which has its own
+// parameters since it is rendered without a tree: the refill is at 26 now, +1.2 % RTIOW against 20, flat from
+// 24 to 28, falling off beyond 32).
 // With parked shapes most lanes can take either step, so the wave stays with one for as long as an
 // eighth of its busy lanes want it (bits 0-7 = 1: +4 % RTIOW, +2 % textured scene against 3).
-constexpr uint32_t PATHS_TUNING_DEFAULT = 1u | (48u << 8) | (20u << 16) | (3u << 30);
+constexpr uint32_t PATHS_TUNING_DEFAULT = 1u | (48u << 8) | (26u << 16) | (3u << 30);
 // a tree too big for LDS: walks are long and differ in length, waiting for 48 finished lanes or 16
 // empty ones leaves the others idle for longer (3,500-shape scene: +4 %; scenes whose tree is in LDS
 // lose 1-3 % with these)
