@@ -194,7 +194,26 @@ def main():
     accum = torch.zeros(H * W * 3, dtype=torch.float64, device=dev) if args.split == "sample" else None
     step_stats = []
 
+    # Tile split over several ranks: the gather of a finished frame's rows (host memory, gloo) runs on a helper
+    # thread while the next frame renders into a second image; every frame is gathered before the clock stops.
+    pipelined = world_size > 1 and args.split == "tile" and len(rank_scenes) == 1
+    images = [out, np.zeros_like(out)] if pipelined else [out]
+    gathers = [None] * len(images)
+    gatherer = None
+    if pipelined:
+        from concurrent.futures import ThreadPoolExecutor
+
+        gatherer = ThreadPoolExecutor(max_workers=1)  # one thread: the ranks issue their gathers in the same order
+    frames = [0]
+
+    def drain():
+        for k, g in enumerate(gathers):
+            if g is not None:
+                g.result()
+                gathers[k] = None
+
     def barrier():
+        drain()
         torch.cuda.synchronize()
         if world_size > 1:
             dist.barrier()
@@ -210,10 +229,16 @@ def main():
             return st
         if args.split == "tile" or world_size == 1:
             # rows interleaved over ranks: tile = one row, rank r owns rows r, r + N, ...
+            k = frames[0] % len(images)
+            frames[0] += 1
+            if gathers[k] is not None:  # the gather that still reads this image
+                gathers[k].result()
+                gathers[k] = None
             _, st = api.render_world(cfg.background, scene, cam, W, H, spp, paths_per_pass=args.paths_per_pass,
-                                     profile=profile, out=out, return_stats=True,
+                                     profile=profile, out=images[k], return_stats=True,
                                      tiles=distributed.row_tiles(W, world_size, rank), handover=(args.handover, 0))
-            distributed.gather_rows(out, rank, world_size, group=gloo)
+            if pipelined:
+                gathers[k] = gatherer.submit(distributed.gather_rows, images[k], rank, world_size, gloo)
         else:
             accum.zero_()
             lo, hi = distributed.sample_range(spp, rank, world_size)  # (never empty: spp >= ranks was checked)

@@ -32,6 +32,9 @@ def sample_range(spp, rank, world_size):
     return (lo, hi) if hi > lo else None
 
 
+_gather_buffers = {}
+
+
 def gather_rows(out, rank, world_size, group=None, dst=0):
     """out: (H, W, 3) uint8 holding this rank's rows; on `dst` it comes back complete."""
     import torch
@@ -39,19 +42,26 @@ def gather_rows(out, rank, world_size, group=None, dst=0):
 
     if world_size == 1:
         return out
-    # gather wants equal shapes: every share is padded to the largest (ranks below H % N own one more row)
+    # gather wants equal shapes: every share is padded to the largest (ranks below H % N own one more row).
+    # The staging tensors are kept between frames (a render loop gathers the same shapes again and again).
     height = out.shape[0]
     most = (height + world_size - 1) // world_size
-    mine = torch.zeros((most,) + out.shape[1:], dtype=torch.uint8)
-    own = np.ascontiguousarray(out[rank::world_size])
-    mine[: own.shape[0]] = torch.from_numpy(own)
+    key = (most,) + tuple(out.shape[1:]) + (world_size, rank == dst)
+    bufs = _gather_buffers.get(key)
+    if bufs is None:
+        mine = torch.zeros((most,) + out.shape[1:], dtype=torch.uint8)
+        parts = [torch.empty_like(mine) for _ in range(world_size)] if rank == dst else None
+        bufs = _gather_buffers[key] = (mine, parts)
+    mine, parts = bufs
+    image = torch.from_numpy(out)  # (a view: rows are copied tensor to tensor, no intermediate arrays)
+    own = image[rank::world_size]
+    mine[: own.shape[0]].copy_(own)
     if rank == dst:
-        parts = [torch.empty_like(mine) for _ in range(world_size)]
         dist.gather(mine, parts, dst=dst, group=group)
         for r in range(world_size):
             if r != dst:
                 n_rows = len(rows_of(r, world_size, height))
-                out[r::world_size] = parts[r][:n_rows].numpy()
+                image[r::world_size].copy_(parts[r][:n_rows])
     else:
         dist.gather(mine, None, dst=dst, group=group)
     return out
