@@ -753,7 +753,11 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     // code -- node visits, shape tests, shading -- that enough lanes are waiting for.
     bool have = false, exhausted = false;
     uint32_t next = 0, chunk_end = 0;  // the wave's chunk of the queue (wave-uniform)
-    const uint32_t chunk = chunk_rays(n, gridDim.x * (PATHS_BLOCK / 64));
+    // (a long queue is taken in longer chunks: consecutive paths are neighbouring pixels, and a wave that stays in one
+    // corner of the image keeps its lanes' rays together -- +0.75 % on the 500-spp frame; on a short queue the waves
+    // would finish further apart than that is worth: -2 % at 64 spp)
+    const uint32_t n_waves = gridDim.x * (PATHS_BLOCK / 64);
+    const uint32_t chunk = n / n_waves >= 65536u ? 2u * CHUNK_RAYS : chunk_rays(n, n_waves);
     uint32_t slot = 0, bounce = 0;
     uint32_t extra_segments = 0;  // closest-hit queries of this wave beyond the first of each path (the same in every lane)
     V3 beta = v3(0.0, 0.0, 0.0);
