@@ -544,4 +544,119 @@ inline BuiltTree build_fast_tree(const mirt_scene_desc* desc, const uint32_t* tk
     return t;
 }
 
+// ---- the culling tree with its bounds as halves (device_scene.h, QNode) ----
+struct QTree {
+    std::vector<QBox> boxes;  // empty: the scene does not lend itself to the format
+    std::vector<QRefs> refs;
+    QGrid grid{};
+    // as the device reads them: the boxes, then the references
+    std::vector<unsigned char> bytes() const {
+        std::vector<unsigned char> out(boxes.size() * sizeof(QBox) + refs.size() * sizeof(QRefs));
+        if (!boxes.empty()) {
+            std::memcpy(out.data(), boxes.data(), boxes.size() * sizeof(QBox));
+            std::memcpy(out.data() + boxes.size() * sizeof(QBox), refs.data(), refs.size() * sizeof(QRefs));
+        }
+        return out;
+    }
+};
+
+namespace accel {
+
+// Every finite IEEE half that is zero or normal, in ascending order.  Subnormal halves are left out:
+// whether an instruction flushes them is a matter of the wave's mode, and a bound must mean one thing.
+struct HalfTable {
+    std::vector<double> value;
+    std::vector<uint16_t> bits;
+    HalfTable() {
+        auto decode = [](uint16_t h) {
+            const int e = (h >> 10) & 31, m = h & 1023;
+            const double mag = std::ldexp(1.0 + m / 1024.0, e - 15);
+            return (h & 0x8000) ? -mag : mag;
+        };
+        for (uint32_t h = 0xFBFFu; h >= 0x8400u; --h) {  // -65504 ... -2^-14
+            value.push_back(decode((uint16_t)h));
+            bits.push_back((uint16_t)h);
+        }
+        value.push_back(0.0);
+        bits.push_back(0);
+        for (uint32_t h = 0x0400u; h <= 0x7BFFu; ++h) {  // 2^-14 ... 65504
+            value.push_back(decode((uint16_t)h));
+            bits.push_back((uint16_t)h);
+        }
+    }
+    // the largest entry <= x / the smallest entry >= x; false when there is none
+    bool below(double x, uint16_t* out) const {
+        const size_t k = std::upper_bound(value.begin(), value.end(), x) - value.begin();
+        if (k == 0) return false;
+        *out = bits[k - 1];
+        return true;
+    }
+    bool above(double x, uint16_t* out) const {
+        const size_t k = std::lower_bound(value.begin(), value.end(), x) - value.begin();
+        if (k == value.size()) return false;
+        *out = bits[k];
+        return true;
+    }
+};
+
+}  // namespace accel
+
+// The nodes of `t` re-expressed as QNodes.  Every bound of every node must be finite and of sane size;
+// at most QNODE_MAX_SHAPES shapes and fewer than QREF_LEAF nodes.
+inline QTree build_qtree(const BuiltTree& t, uint32_t n_shapes) {
+    using namespace accel;
+    QTree q;
+    if (t.nodes.empty() || t.nodes.size() >= QREF_LEAF || n_shapes > QNODE_MAX_SHAPES) return q;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) lo[a] = std::numeric_limits<double>::infinity(), hi[a] = -lo[a];
+    for (const CNode& n : t.nodes)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 2; ++c) {
+                const double l = n.b[a][0][c], h = n.b[a][1][c];
+                if (!std::isfinite(l) || !std::isfinite(h) || std::fabs(l) > 1.0e15 || std::fabs(h) > 1.0e15) return q;
+                lo[a] = std::fmin(lo[a], l);
+                hi[a] = std::fmax(hi[a], h);
+            }
+    for (int a = 0; a < 3; ++a) {
+        q.grid.center[a] = 0.5 * lo[a] + 0.5 * hi[a];
+        const double half_extent = std::fmax(hi[a] - q.grid.center[a], q.grid.center[a] - lo[a]);
+        // a power of two that brings the half extent to at most 2^14 grid units: far from both ends of a half's range
+        int e = 0;
+        if (half_extent > 0.0) {
+            (void)std::frexp(half_extent, &e);  // half_extent = m * 2^e, 0.5 <= m < 1
+            e -= 14;
+        }
+        if (e < -60 || e > 60) return q;
+        q.grid.step[a] = (float)std::ldexp(1.0, e);
+    }
+    static const HalfTable table;
+    q.boxes.resize(t.nodes.size());
+    q.refs.resize(t.nodes.size());
+    double reach[3] = {0.0, 0.0, 0.0};
+    for (size_t k = 0; k < t.nodes.size(); ++k) {
+        const CNode& n = t.nodes[k];
+        QBox& out = q.boxes[k];
+        for (int c = 0; c < 2; ++c) {
+            for (int a = 0; a < 3; ++a) {
+                const double step = q.grid.step[a];
+                // (b - center) / step: the subtraction rounds (2^-53 of the larger term), the division is exact
+                const double l = (n.b[a][0][c] - q.grid.center[a]) / step, h = (n.b[a][1][c] - q.grid.center[a]) / step;
+                const double slack_l = (std::fabs(n.b[a][0][c]) + std::fabs(q.grid.center[a])) / step * 0x1.0p-50;
+                const double slack_h = (std::fabs(n.b[a][1][c]) + std::fabs(q.grid.center[a])) / step * 0x1.0p-50;
+                if (!table.below(l - slack_l, &out.b[a][c][0]) || !table.above(h + slack_h, &out.b[a][c][1])) {
+                    q.boxes.clear();
+                    q.refs.clear();
+                    return q;
+                }
+                reach[a] = std::fmax(reach[a], std::fmax(std::fabs(l), std::fabs(h)) + 32.0);
+            }
+            const uint32_t ref = n.child[c];
+            if (ref & REF_LEAF) q.refs[k].child[c] = (uint16_t)(QREF_LEAF | (((ref >> REF_KIND_SHIFT) & 7u) << QREF_KIND_SHIFT) | (ref & REF_INDEX_MASK));
+            else q.refs[k].child[c] = (uint16_t)ref;
+        }
+    }
+    for (int a = 0; a < 3; ++a) q.grid.half[a] = f32_above(reach[a]);
+    return q;
+}
+
 }  // namespace mirt

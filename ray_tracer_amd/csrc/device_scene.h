@@ -39,6 +39,34 @@ struct alignas(8) CNode {
 };
 static_assert(sizeof(CNode) == 56, "CNode is 56 bytes");
 
+// The same tree in half the bytes, for scenes whose 56-byte nodes do not fit the CU's LDS but whose
+// 28-byte ones do (up to ~3 700 shapes): every bound as an IEEE half, in units of `QGrid::step` from
+// `QGrid::center` per axis, rounded outward on the host (accel_build.h, build_qtree).  One 8-byte read
+// fetches an axis: a dword per child with the lower bound in its low half and the upper in its high; a
+// rotation by 0 or 16 bits (the ray's direction along the axis) puts the near bound low, and
+// v_fma_mix_f32 takes either half as an operand, so a node visit needs no conversion instructions.
+// A half resolves 2^-11 of a bound's distance from the centre: the boxes come out that much larger than
+// the f32 ones, which costs shape tests and no answer.
+//   QBox::b[axis][c][0 / 1] = lower / upper bound of child c (bits of a half)
+//   QRefs::child[c]         = inner node: its index (< QREF_LEAF);
+//                             leaf: QREF_LEAF | TraverseKind << QREF_KIND_SHIFT | index of the shape
+// In memory: all QBoxes (24 bytes each, so 8-byte reads stay aligned), then all QRefs.
+struct alignas(8) QBox {
+    uint16_t b[3][2][2];
+};
+struct alignas(4) QRefs {
+    uint16_t child[2];
+};
+static_assert(sizeof(QBox) == 24 && sizeof(QRefs) == 4, "a QNode is 24 + 4 bytes");
+constexpr uint32_t QNODE_BYTES = sizeof(QBox) + sizeof(QRefs);
+constexpr uint32_t QREF_LEAF = 0x8000u, QREF_KIND_SHIFT = 12, QREF_INDEX_MASK = 0xFFFu;
+constexpr uint32_t QNODE_MAX_SHAPES = QREF_INDEX_MASK + 1u;
+struct QGrid {
+    double center[3];  // world coordinate of grid coordinate 0
+    float step[3];     // world length of one grid unit: a power of two
+    float half[3];     // largest magnitude of a grid coordinate of the tree
+};
+
 // The boxes of the reference's tree that decide whether a shape is tested at all: in the
 // reference a leaf is reached iff AABB::hit passes for every BVHMember::Node above it
 // (src/bvh.rs:61-66).  gate_of[shape] names the gate of the shape's parent node; `next`
@@ -83,7 +111,7 @@ enum TraverseKind : uint32_t {
 //   f[0..8]    parameters of the fast traversal
 //                TK_SPHERE          {c0x, c0y, c0z, radius, c1x - c0x, c1y - c0y, c1z - c0z, ts, 1 / (te - ts)}
 //                every other kind   the shape's own parameters (mirt_shape.f)
-//   material   index into DScene::materials
+//   material   index into DScene::materials | ShadeClass of the material << REC_CLASS_SHIFT
 //   texture    lambertian / diffuse light whose texture is not a constant: index into
 //              DScene::shade_textures; NO_TEXTURE otherwise
 //   color      lambertian / diffuse light with a constant texture: its colour; metal: albedo
@@ -91,6 +119,7 @@ enum TraverseKind : uint32_t {
 //   sure       [axis][lo, hi]: the box of the shape's gate moved INWARD (accel_build.h); a ray that
 //              provably crosses it needs no exact gate test (RayWalk::confirm)
 constexpr uint32_t NO_TEXTURE = 0xFFFFFFFFu;
+constexpr uint32_t REC_CLASS_SHIFT = 28, REC_MATERIAL_MASK = (1u << REC_CLASS_SHIFT) - 1u;
 struct alignas(8) ShapeRec {
     double f[9];
     uint32_t material;
@@ -171,6 +200,8 @@ struct DScene {
     uint32_t n_scan_items;           // 0: the scene has too many shapes to be rendered without a tree
     const ScanBoxes* scan_boxes;     // culling boxes of the items, two per entry
     const ScanItem* scan_items;
+    const QBox* qnodes;              // the culling tree with bounds as halves (same numbering as `nodes`): n_nodes QBoxes, then n_nodes QRefs; or null
+    QGrid qgrid;
 };
 
 }  // namespace mirt

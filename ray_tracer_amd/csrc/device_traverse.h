@@ -88,11 +88,21 @@ __device__ __forceinline__ uint2 lds_read_u32x2(uint32_t addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
+template <int OFFSET>
+__device__ __forceinline__ uint32_t lds_read_u32(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
+    return v;
+}
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);  // nothing that reads the values may be hoisted above the wait
 }
 
+#ifdef MIRT_PATHS_STATS
+// development build: walks begun without culling allowed, with a ray that is not tame, and in all
+__device__ unsigned long long g_walk_stats[4];
+#endif
 enum TraverseStat : int {
     STAT_OUTER_ITERS = 0,  // trips of the outer loop, per wave
     STAT_NODE_ITERS,       // wave-level node visits (trips of the inner loop)
@@ -160,6 +170,37 @@ struct CullRay {
         far_z = (f32x2){far[2], 0.0f};
         tame = cull && size < 1.0e18f;  // false for a NaN
     }
+    // The same constants for a tree whose bounds are halves in grid units (device_scene.h, QNode): the
+    // bound g maps to t = g * (step * inv) + c with c = (center - o) * inv -+ E.  Against the exact
+    // (center + g * step - o) / d the computed t carries relative errors of at most 2^-22 (rounding d and
+    // center - o to f32, v_rcp_f32, the product, the FMA), proportional to |g * step * inv| <= half * |step * inv|
+    // or to |(center - o) * inv|: E = 2^-19 of their sum, eight times what is needed.  A ray whose terms
+    // are not all finite and of sane size is not culled at all (`tame` is the culling flag here): with
+    // every term finite no NaN arises and nothing rests on one being dropped.
+    __device__ __forceinline__ void set_q(const RayD& r, bool cull, const QGrid& grid) {
+        const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+        float size = 0.0f, inv_q[3], c[3], e[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float i32 = __builtin_amdgcn_rcpf((float)d[a]);
+            const float p = (float)(grid.center[a] - o[a]) * i32;
+            inv_q[a] = i32 * grid.step[a];
+            e[a] = (__builtin_fabsf(p) + __builtin_fabsf(inv_q[a]) * grid.half[a]) * 0x1.0p-19f;
+            size += __builtin_fabsf(i32) + __builtin_fabsf(p) + __builtin_fabsf(inv_q[a]) * grid.half[a];
+            c[a] = p;
+            off[a] = i32 < 0.0f ? 16u : 0u;  // the rotation that brings the near bound of a QBox dword into its low half
+        }
+        tame = cull && size < 1.0e18f;  // false for a NaN
+        float far[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ic[a].x = tame ? inv_q[a] : 0.0f;
+            ic[a].y = tame ? c[a] - e[a] : -__builtin_inff();
+            far[a] = tame ? c[a] + e[a] : __builtin_inff();
+        }
+        far_xy = (f32x2){far[0], far[1]};
+        far_z = (f32x2){far[2], 0.0f};
+    }
     // Does the ray cross `box` ([axis][lo, hi], f32, already moved inward by the host) somewhere
     // in (t_lo, t_hi), beyond what rounding could undo?  The mirror image of slab_pair: the near
     // bound with the FAR constant bounds the entry from above, the far bound with the NEAR
@@ -204,6 +245,45 @@ __device__ __forceinline__ void slab_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32x2 fy
         : "=&v"(in0), "=&v"(in1), "=&v"(out0), "=&v"(out1)
         : "v"(tnx.x), "v"(tny.x), "v"(tnz.x), "v"(tnx.y), "v"(tny.y), "v"(tnz.y), "v"(tfx.x), "v"(tfy.x), "v"(tfz.x), "v"(tfx.y), "v"(tfy.y),
           "v"(tfz.y), "v"(t_lo), "v"(t_hi));
+    *e0 = in0;
+    *e1 = in1;
+    *pass0 = !(out0 < in0);
+    *pass1 = !(out1 < in1);
+}
+
+// The same for bounds that are halves (QBox): x0 = child 0's x bounds, near in the low and far in the high
+// half, and so on; v_fma_mix_f32 converts the half it is pointed at on the way in.
+__device__ __forceinline__ void slab_pair_q(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, const CullRay& c,
+                                            float t_lo, float t_hi, float* e0, float* e1, bool* pass0, bool* pass1) {
+    float tn0x, tn1x, tn0y, tn1y, tn0z, tn1z, tf0x, tf1x, tf0y, tf1y, tf0z, tf1z;
+    asm("v_fma_mix_f32 %0, %12, %18, %19 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %13, %18, %19 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %14, %20, %21 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %15, %20, %21 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %16, %22, %23 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %17, %22, %23 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %6, %12, %18, %24 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %7, %13, %18, %24 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %8, %14, %20, %25 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %9, %15, %20, %25 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %10, %16, %22, %26 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %11, %17, %22, %26 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(tn0x), "=&v"(tn1x), "=&v"(tn0y), "=&v"(tn1y), "=&v"(tn0z), "=&v"(tn1z), "=&v"(tf0x), "=&v"(tf1x), "=&v"(tf0y), "=&v"(tf1y),
+          "=&v"(tf0z), "=&v"(tf1z)
+        : "v"(x0), "v"(x1), "v"(y0), "v"(y1), "v"(z0), "v"(z1), "v"(c.ic[0].x), "v"(c.ic[0].y), "v"(c.ic[1].x), "v"(c.ic[1].y), "v"(c.ic[2].x),
+          "v"(c.ic[2].y), "v"(c.far_xy.x), "v"(c.far_xy.y), "v"(c.far_z.x));
+    float in0, in1, out0, out1;
+    asm("v_max_f32 %0, %4, %5\n\t"
+        "v_max_f32 %1, %7, %8\n\t"
+        "v_min_f32 %2, %10, %11\n\t"
+        "v_min_f32 %3, %13, %14\n\t"
+        "v_max3_f32 %0, %0, %6, %16\n\t"
+        "v_max3_f32 %1, %1, %9, %16\n\t"
+        "v_min3_f32 %2, %2, %12, %17\n\t"
+        "v_min3_f32 %3, %3, %15, %17"
+        : "=&v"(in0), "=&v"(in1), "=&v"(out0), "=&v"(out1)
+        : "v"(tn0x), "v"(tn0y), "v"(tn0z), "v"(tn1x), "v"(tn1y), "v"(tn1z), "v"(tf0x), "v"(tf0y), "v"(tf0z), "v"(tf1x), "v"(tf1y), "v"(tf1z),
+          "v"(t_lo), "v"(t_hi));
     *e0 = in0;
     *e1 = in1;
     *pass0 = !(out0 < in0);
@@ -275,8 +355,10 @@ __device__ __noinline__ HitRec reference_answer(const mirt_bvh_member* __restric
 // ODDITIES: rays whose answer depends on the reference's order of evaluation (reference_answer) are
 // recognised and handed to it.
 // stack: LDS, [level][BLOCK] entries of StackT, this lane's column is `tid`.
-template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS, bool ODDITIES = true, int PARK = 2>
+// QNODES: the tree is read as QNodes (bounds as halves, 16-bit child references; device_scene.h) from LDS.
+template <int BLOCK, class StackT, bool NODES_IN_LDS, bool SHAPES_IN_LDS, bool ODDITIES = true, int PARK = 2, bool QNODES = false>
 struct RayWalk {
+    static_assert(!QNODES || (NODES_IN_LDS && !SHAPES_IN_LDS && !ODDITIES), "QNodes live in LDS, their shapes' records in global memory");
     // best.side of a hit found by a walk: cube side | ShadeClass << 4 | TraverseKind << 7
     // (bits 23..28 of the leaf reference, moved down as they are)
     static constexpr uint32_t SIDE_MASK = 15u, CLASS_SHIFT = 4, TK_SHIFT = 7;
@@ -294,7 +376,9 @@ struct RayWalk {
     // register pair instead, lowest = next out; the LDS copy of the tree holds its leaf references in
     // that form (stage_tree).  Parking is a shift and an or, and there is no count to keep: a reference
     // is never zero, so the low word is zero iff nothing is parked and the high word iff at most two are.
-    static constexpr bool PACKED = NODES_IN_LDS && PARK == 4;
+    // QNODES: the references are 16 bits as they come; with PARK = 2 a node visit still waits until nothing is parked.
+    static constexpr bool PACKED = NODES_IN_LDS && (PARK == 4 || QNODES);
+    static constexpr bool PACKED_EAGER = PACKED && PARK == 4;  // a node visit while at most two shapes are parked
     uint32_t parked_lo, parked_hi;
     bool careful;  // second walk: a hit counts only if its shape's gates pass
     bool weird;    // a NaN t or a time that is not finite was met: see reference_answer
@@ -309,13 +393,14 @@ struct RayWalk {
         weird = false;
     }
     __device__ __forceinline__ bool wants_node() const {
-        return (PACKED ? parked_hi == 0u : nq <= (uint32_t)(PARK - 2)) && cur != CUR_DONE;
+        return (PACKED ? (PACKED_EAGER ? parked_hi : parked_lo) == 0u : nq <= (uint32_t)(PARK - 2)) && cur != CUR_DONE;
     }
     __device__ __forceinline__ bool wants_leaf() const { return PACKED ? parked_lo != 0u : nq != 0; }
     // The wave's lanes that want a node visit / a shape test, as masks: one vote per comparison, combined
     // as masks (the vote on a combined flag goes through a vector select and a second comparison).
     __device__ __forceinline__ unsigned long long vote_node() const {
-        return __builtin_amdgcn_ballot_w64(PACKED ? parked_hi == 0u : nq <= (uint32_t)(PARK - 2)) & __builtin_amdgcn_ballot_w64(cur != CUR_DONE);
+        return __builtin_amdgcn_ballot_w64(PACKED ? (PACKED_EAGER ? parked_hi : parked_lo) == 0u : nq <= (uint32_t)(PARK - 2)) &
+               __builtin_amdgcn_ballot_w64(cur != CUR_DONE);
     }
     __device__ __forceinline__ unsigned long long vote_leaf() const { return __builtin_amdgcn_ballot_w64(PACKED ? parked_lo != 0u : nq != 0); }
     __device__ __forceinline__ bool finished() const { return (PACKED ? parked_lo == 0u : nq == 0) && cur == CUR_DONE; }
@@ -347,7 +432,11 @@ struct RayWalk {
         clear_parked();
         best = HitRec{0.0, -1, 0};
         const uint32_t root = sc.root_ref;
-        if (root & REF_LEAF) park(PACKED ? ref16_of(root) : root);  // a one-shape world: bare leaf (bvh.rs:179-180)
+        // a one-shape world: bare leaf (bvh.rs:179-180)
+        if (root & REF_LEAF)
+            park(QNODES   ? QREF_LEAF | (((root >> REF_KIND_SHIFT) & 7u) << QREF_KIND_SHIFT) | (root & REF_INDEX_MASK)
+                 : PACKED ? ref16_of(root)
+                          : root);
         else cur = root;
     }
 
@@ -356,8 +445,15 @@ struct RayWalk {
         // a moving sphere's box holds for times inside its own span only; and the boxes say nothing
         // about what the sphere test makes of a ray that starts too far away (accel_build.h, cull_reach)
         const float from = fmaxf(fmaxf(__builtin_fabsf((float)r.o.x), __builtin_fabsf((float)r.o.y)), __builtin_fabsf((float)r.o.z));
-        cull.set(r, r.time >= sc.time_lo && r.time <= sc.time_hi && from <= sc.cull_reach &&
-                        r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z);
+        const bool may_cull = r.time >= sc.time_lo && r.time <= sc.time_hi && from <= sc.cull_reach &&
+                              r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z;
+        if (QNODES) cull.set_q(r, may_cull, sc.qgrid);
+        else cull.set(r, may_cull);
+#ifdef MIRT_PATHS_STATS
+        if (!may_cull) atomicAdd(&g_walk_stats[0], 1ull);
+        if (!cull.tame) atomicAdd(&g_walk_stats[1], 1ull);
+        atomicAdd(&g_walk_stats[2], 1ull);
+#endif
         careful = false;
         weird = false;
         if (ODDITIES) {
@@ -394,7 +490,14 @@ struct RayWalk {
         if (careful || best.prim < 0) return true;
         const ShapeRec* rec = SHAPES_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)best.prim * SHAPE_LDS_BYTES)
                                             : sc.recs + best.prim;
-        if (cull.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) return true;
+        if (QNODES) {
+            // the record's box is in world coordinates: the ray's constants for those, once per ray
+            CullRay plain;
+            plain.set(r, cull.tame);
+            if (plain.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) return true;
+        } else if (cull.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) {
+            return true;
+        }
         return gates_pass(sc.gates, sc.gate_of, (uint32_t)best.prim, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max);
     }
     __device__ __forceinline__ void begin_careful(const DScene& sc, double t_min, double t_max) {
@@ -408,7 +511,21 @@ struct RayWalk {
         uint32_t c0, c1;
         float e0, e1;
         bool pass0, pass1;
-        if (NODES_IN_LDS) {
+        if (QNODES) {
+            // three 8-byte reads (one per axis: both children's bounds) and the references, issued back to back, one wait
+            const uint32_t box = (uint32_t)(size_t)lds.nodes + __umul24(cur, (uint32_t)sizeof(QBox));
+            const uint32_t ref = (uint32_t)(size_t)lds.shapes + cur * (uint32_t)sizeof(QRefs);  // (the QRefs follow the QBoxes)
+            const uint32_t refs = lds_read_u32<0>(ref);
+            const uint2 x = lds_read_u32x2<0>(box), y = lds_read_u32x2<8>(box), z = lds_read_u32x2<16>(box);
+            lds_wait();
+            c0 = refs & 0xFFFFu;
+            c1 = refs >> 16;
+            // near bound into the low half, far bound into the high half of each child's dword
+            slab_pair_q(__builtin_amdgcn_alignbit(x.x, x.x, cull.off[0]), __builtin_amdgcn_alignbit(x.y, x.y, cull.off[0]),
+                        __builtin_amdgcn_alignbit(y.x, y.x, cull.off[1]), __builtin_amdgcn_alignbit(y.y, y.y, cull.off[1]),
+                        __builtin_amdgcn_alignbit(z.x, z.x, cull.off[2]), __builtin_amdgcn_alignbit(z.y, z.y, cull.off[2]), cull, t_lo, t_hi, &e0,
+                        &e1, &pass0, &pass1);
+        } else if (NODES_IN_LDS) {
             // seven 8-byte reads of one node, issued back to back, one wait
             // (LDS byte address = the low half of the generic address of an LDS object)
             const uint32_t node = (uint32_t)(size_t)lds.nodes + __umul24(cur, (uint32_t)NODE_LDS_BYTES);  // (one v_mad_u32_u24)
@@ -465,7 +582,7 @@ struct RayWalk {
             }
             slab_pair(nx, fx, ny, fy, nz, fz, cull, t_lo, t_hi, &e0, &e1, &pass0, &pass1);
         }
-        const bool leaf0 = (c0 & REF_LEAF) != 0, leaf1 = (c1 & REF_LEAF) != 0;
+        const bool leaf0 = (c0 & (QNODES ? QREF_LEAF : REF_LEAF)) != 0, leaf1 = (c1 & (QNODES ? QREF_LEAF : REF_LEAF)) != 0;
         // (the same decisions written two ways: how the compiler lays out the compares and branches is worth
         // +1.2 % on the RTIOW scene for the first form with the tree in LDS, and -0.9 % on the 3,500-shape scene,
         // whose nodes come from global memory)
@@ -509,9 +626,9 @@ struct RayWalk {
             const uint32_t entry = parked_lo & 0xFFFFu;
             parked_lo = __builtin_amdgcn_alignbit(parked_hi, parked_lo, 16);
             parked_hi >>= 16;
-            index = entry & REF16_INDEX_MASK;
-            tk = entry >> REF16_KIND_SHIFT;
-            class_and_kind = entry >> REF16_CLASS_SHIFT;
+            index = entry & (QNODES ? QREF_INDEX_MASK : REF16_INDEX_MASK);
+            tk = QNODES ? (entry >> QREF_KIND_SHIFT) & 7u : entry >> REF16_KIND_SHIFT;
+            class_and_kind = QNODES ? tk << 3 : entry >> REF16_CLASS_SHIFT;  // QNODES: the class comes from the record, below
         } else {
             const uint32_t entry = q[0];
 #pragma unroll
@@ -523,6 +640,7 @@ struct RayWalk {
         }
         double local[9];
         const double* p = sc.recs[SHAPES_IN_LDS ? 0u : index].f;
+        if (QNODES) class_and_kind |= sc.recs[index].material >> REC_CLASS_SHIFT;
         if (SHAPES_IN_LDS) {
             // the nine parameters as nine single reads issued back to back (see lds_read_f32x2)
             const uint32_t rec = (uint32_t)(size_t)lds.shapes + __umul24(index, (uint32_t)SHAPE_LDS_BYTES);

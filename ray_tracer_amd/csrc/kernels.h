@@ -169,6 +169,9 @@ __host__ __device__ inline size_t trav_stack_bytes(uint32_t levels, size_t entry
 __host__ __device__ inline size_t trav_nodes_bytes(uint32_t n_nodes) {
     return (((size_t)n_nodes * NODE_LDS_BYTES) + 15) & ~(size_t)15;
 }
+__host__ __device__ inline size_t qnodes_bytes(uint32_t n_nodes) {
+    return (((size_t)n_nodes * QNODE_BYTES) + 15) & ~(size_t)15;
+}
 __host__ __device__ inline size_t scan_boxes_bytes(uint32_t n_pairs) {
     return (((size_t)n_pairs * sizeof(ScanBoxes)) + 15) & ~(size_t)15;
 }
@@ -652,6 +655,8 @@ constexpr uint32_t PATHS_TUNING_DEFAULT = 1u | (48u << 8) | (26u << 16) | (3u <<
 // empty ones leaves the others idle for longer (3,500-shape scene: +4 %; scenes whose tree is in LDS
 // lose 1-3 % with these)
 constexpr uint32_t PATHS_TUNING_BIG_TREE = 3u | (44u << 8) | (8u << 16) | (1u << 30);
+// nodes in LDS as QNodes, records in global memory
+constexpr uint32_t PATHS_TUNING_QNODES = PATHS_TUNING_BIG_TREE;
 // no tree (ScanWalk): after a scan every lane is ready for shading, so shading never waits; the refill
 // threshold is what there is to choose
 constexpr uint32_t PATHS_TUNING_SCAN = 1u | (1u << 8) | (16u << 16) | (3u << 30);
@@ -670,6 +675,10 @@ constexpr uint32_t PATHS_TUNING_SCAN = 1u | (1u << 8) | (16u << 16) | (3u << 30)
 #endif
 #ifndef MIRT_PARK_BIG
 #define MIRT_PARK_BIG 2
+#endif
+// ... and with the nodes in LDS as QNodes and the records in global memory
+#ifndef MIRT_PARK_QNODES
+#define MIRT_PARK_QNODES 4
 #endif
 
 // A kernel argument read from the argument block (constant address space: scalar loads) at byte `offset`.
@@ -694,7 +703,8 @@ enum : int {
     TREE_GLOBAL = 0,     // both from global memory
     TREE_LDS = 1,        // both staged in LDS
     TREE_NODES_LDS = 2,  // the nodes in LDS, the records (2.4 times their size) from global memory
-    TREE_SCAN = 3        // a handful of rects and cubes: no tree, every ray against the box of every rect and face (ScanWalk)
+    TREE_SCAN = 3,       // a handful of rects and cubes: no tree, every ray against the box of every rect and face (ScanWalk)
+    TREE_QNODES_LDS = 4  // the nodes in LDS as QNodes (28 bytes, bounds as halves), the records from global memory
 };
 template <class StackT, int TEXTURES, int TREE>
 __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_per_eu(paths_waves(TEXTURES)))) void k_paths(
@@ -702,7 +712,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     constexpr int PATHS_BLOCK = paths_block(TEXTURES);
     constexpr bool HAS_NOISE = TEXTURES >= TEXTURES_ALL;
     constexpr bool SCAN = TREE == TREE_SCAN;
-    constexpr bool TREE_IN_LDS = TREE == TREE_LDS, NODES_IN_LDS = TREE == TREE_LDS || TREE == TREE_NODES_LDS;
+    constexpr bool QNODES = TREE == TREE_QNODES_LDS;
+    constexpr bool TREE_IN_LDS = TREE == TREE_LDS, NODES_IN_LDS = TREE == TREE_LDS || TREE == TREE_NODES_LDS || QNODES;
     constexpr bool RECS_IN_LDS = TREE_IN_LDS || SCAN;  // the shapes' records, as shading reads them
     // dynamic LDS: [level][PATHS_BLOCK] stack entries, the first n_top nodes of the tree (TREE_IN_LDS: all of
     // them), and (TREE_IN_LDS) the shapes' records
@@ -725,10 +736,10 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     }
     StackT* stack = reinterpret_cast<StackT*>(smem);
     char* lds_nodes = smem + trav_stack_bytes(stack_levels, sizeof(StackT), PATHS_BLOCK);
-    char* lds_shapes = lds_nodes + (TREE == TREE_SCAN ? scan_boxes_bytes(n_top) : trav_nodes_bytes(n_top));
-    typedef RayWalk<PATHS_BLOCK, StackT, NODES_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : MIRT_PARK_BIG> TreeWalk;
+    char* lds_shapes = lds_nodes + (TREE == TREE_SCAN ? scan_boxes_bytes(n_top) : QNODES ? qnodes_bytes(n_top) : trav_nodes_bytes(n_top));
+    typedef RayWalk<PATHS_BLOCK, StackT, NODES_IN_LDS, TREE_IN_LDS, false, TREE_IN_LDS ? MIRT_PARK : QNODES ? MIRT_PARK_QNODES : MIRT_PARK_BIG, QNODES> TreeWalk;
     typedef typename std::conditional<SCAN, ScanWalk<PATHS_BLOCK>, TreeWalk>::type Walk;
-    static_assert(!Walk::PACKED || TREE_IN_LDS, "16-bit parked references need the at most 1 024 shapes of a tree that is in LDS as a whole");
+    static_assert(!Walk::PACKED || TREE_IN_LDS || QNODES, "16-bit parked references: a tree that is in LDS as a whole (at most 1 024 shapes), or QNodes (at most 4 096)");
     // SCAN: n_top = the pairs of item boxes (DScene::scan_boxes), the items follow the shapes' records
     char* lds_items = lds_shapes + (((size_t)sc.n_shapes * SHAPE_LDS_BYTES + 15) & ~(size_t)15);
     if (SCAN) {
@@ -739,8 +750,17 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
         dst = reinterpret_cast<uint32_t*>(lds_items);
         for (uint32_t w = threadIdx.x; w < sc.n_scan_items * (uint32_t)(sizeof(ScanItem) / 4); w += PATHS_BLOCK) dst[w] = src[w];
     }
-    stage_tree<PATHS_BLOCK, !SCAN, RECS_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
-    const TraverseLds lds{lds_nodes, lds_shapes, n_top, SCAN ? lds_items : nullptr, SCAN ? sc.n_scan_items : 0u};
+    if (QNODES) {
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.qnodes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_nodes);
+        for (uint32_t w = threadIdx.x; w < n_top * (QNODE_BYTES / 4); w += PATHS_BLOCK) dst[w] = src[w];
+        __syncthreads();
+    } else {
+        stage_tree<PATHS_BLOCK, !SCAN, RECS_IN_LDS, Walk::PACKED>(sc, lds_nodes, lds_shapes, n_top);
+    }
+    // (QNODES: no records in LDS; `shapes` is where the QRefs begin)
+    const TraverseLds lds{lds_nodes, QNODES ? lds_nodes + (size_t)n_top * sizeof(QBox) : lds_shapes, n_top, SCAN ? lds_items : nullptr,
+                          SCAN ? sc.n_scan_items : 0u};
 
     const Counters C{rp.max_depth};
     const uint32_t n = bounce0 == 0 ? rp.n_paths : P.counters[C.live(bounce0)];

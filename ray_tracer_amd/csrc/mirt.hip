@@ -220,6 +220,7 @@ static int validate_desc(const mirt_scene_desc* d) {
     if (!d->shapes || d->n_shapes == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene has no shapes");
     if (d->n_shapes > MAX_SHAPES) return fail(MIRT_ERR_UNSUPPORTED, "more than %u shapes", MAX_SHAPES);
     if (!d->materials || d->n_materials == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene has no materials");
+    if (d->n_materials > REC_MATERIAL_MASK) return fail(MIRT_ERR_UNSUPPORTED, "more than %u materials", REC_MATERIAL_MASK);
     if (d->n_textures && !d->textures) return fail(MIRT_ERR_INVALID_ARGUMENT, "textures is null");
     if (d->n_perlins && !d->perlins) return fail(MIRT_ERR_INVALID_ARGUMENT, "perlins is null");
     if (d->n_images && !d->images) return fail(MIRT_ERR_INVALID_ARGUMENT, "images is null");
@@ -347,6 +348,7 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
     for (uint32_t i = 0; i < desc->n_shapes; ++i) {
         shapes[i].tk = tkinds[i];
         ref_bits[i] = (tkinds[i] << REF_KIND_SHIFT) | (shapes[i].cls << REF_CLASS_SHIFT);
+        recs[i].material |= shapes[i].cls << REC_CLASS_SHIFT;
     }
     BuiltTree tree;
     if (desc->nodes) {
@@ -365,6 +367,8 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
             return fail(MIRT_ERR_UNSUPPORTED, "BVH is %u levels deep; at most %d are supported", deepest, MAX_TREE_HEIGHT);
     }
     if (desc->nodes) sure_boxes(tree, &recs);
+    QTree qtree;
+    if (desc->nodes) qtree = build_qtree(tree, desc->n_shapes);
     std::vector<ScanBoxes> scan_boxes;
     std::vector<ScanItem> scan_items;
     if (desc->nodes && desc->n_shapes <= 4 * MIRT_SCAN_MAX_SHAPES) build_scan_items(desc, recs, ref_bits.data(), &scan_boxes, &scan_items);
@@ -417,6 +421,9 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
     SCENE_TRY(upload(&d_recs, recs.data(), recs.size()));
     SCENE_TRY(upload(&d_shade_textures, shade_textures.data(), shade_textures.size()));
     SCENE_TRY(upload(&d_nodes, nodes.data(), nodes.size()));
+    unsigned char* d_qnodes = nullptr;
+    const std::vector<unsigned char> qbytes = qtree.bytes();
+    if (!qbytes.empty()) SCENE_TRY(upload(&d_qnodes, qbytes.data(), qbytes.size()));
     ScanBoxes* d_scan_boxes = nullptr;
     ScanItem* d_scan_items = nullptr;
     SCENE_TRY(upload(&d_scan_boxes, scan_boxes.data(), scan_boxes.size()));
@@ -445,6 +452,8 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
     sc->d.scan_boxes = d_scan_boxes;
     sc->d.scan_items = d_scan_items;
     sc->d.n_scan_items = (uint32_t)scan_items.size();
+    sc->d.qnodes = reinterpret_cast<const QBox*>(d_qnodes);
+    sc->d.qgrid = qtree.grid;
     sc->d.gates = d_gates;
     sc->d.gate_of = d_gate_of;
     sc->d.time_lo = tree.time_lo;
@@ -783,6 +792,7 @@ struct PathsPlan {
     bool stack16 = true;
     bool tree_in_lds = false;
     bool nodes_in_lds = false;  // the nodes alone (records from global memory)
+    bool qnodes_in_lds = false; // ... as QNodes
     bool scan = false;          // no tree: every shape tested for every ray
     int block = 256;
     size_t lds_bytes = 0;
@@ -835,7 +845,18 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
         p.kernel = paths_kernel_for<uint16_t, TREE_LDS>(textures);
     } else {
         const size_t room = TRAV_LDS_BUDGET > stack + fixed ? TRAV_LDS_BUDGET - stack - fixed : 0;
-        if (MIRT_NODES_IN_LDS && p.stack16 && scene->d.n_nodes > 0 && nodes <= room) {
+        // development aid: MIRT_QNODES=0 keeps QNodes out, =2 prefers them to 56-byte nodes that would fit too
+        static const int qnodes_mode = [] {
+            const char* s = std::getenv("MIRT_QNODES");
+            return s ? std::atoi(s) : 1;
+        }();
+        const bool qnodes_fit = qnodes_mode && p.stack16 && scene->d.qnodes && qnodes_bytes(scene->d.n_nodes) <= room;
+        if (qnodes_fit && (qnodes_mode == 2 || nodes > room)) {
+            p.qnodes_in_lds = true;
+            p.n_top = scene->d.n_nodes;
+            p.lds_bytes = stack + qnodes_bytes(scene->d.n_nodes);
+            p.kernel = paths_kernel_for<uint16_t, TREE_QNODES_LDS>(textures);
+        } else if (MIRT_NODES_IN_LDS && p.stack16 && scene->d.n_nodes > 0 && nodes <= room) {
             // the nodes fit on their own: every node visit from LDS, the records from global memory
             p.nodes_in_lds = true;
             p.n_top = scene->d.n_nodes;
@@ -854,6 +875,14 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, p.kernel, p.block, p.lds_bytes) != hipSuccess || n <= 0) n = 1;
     p.per_cu = std::min(n, 8);
+    // development aid: MIRT_PLAN_VERBOSE=1 says on stderr how the path kernel is launched
+    static const bool verbose = [] {
+        const char* s = std::getenv("MIRT_PLAN_VERBOSE");
+        return s && s[0] == '1';
+    }();
+    if (verbose)
+        std::fprintf(stderr, "[mirt plan] shapes=%u nodes=%u levels=%u block=%d lds=%zu tree=%s per_cu=%d\n", scene->d.n_shapes, scene->d.n_nodes, p.levels,
+                     p.block, p.lds_bytes, p.scan ? "scan" : p.tree_in_lds ? "lds" : p.qnodes_in_lds ? "qnodes" : p.nodes_in_lds ? "nodes-lds" : "global", p.per_cu);
     *out = p;
     return hipSuccess;
 }
@@ -872,6 +901,7 @@ hipError_t launch_paths(const mirt_scene* scene, const PathsPlan& plan, const Pa
     const uint32_t tuning_default = tuning_override ? tuning_override
                                     : plan.scan     ? PATHS_TUNING_SCAN
                                     : plan.tree_in_lds ? PATHS_TUNING_DEFAULT
+                                    : plan.qnodes_in_lds ? PATHS_TUNING_QNODES
                                                        : PATHS_TUNING_BIG_TREE;
     DScene sc = scene->d;
     Paths paths = P;
@@ -1158,6 +1188,9 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         const char* parts[8] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "next ray / store"};
         for (int k = 0; k < 8; ++k)
             std::fprintf(stderr, "[k_paths]   shade: %-20s %5.1f %% of wave clocks\n", parts[k], 100.0 * (double)segments[2 + 13 + k] / total);
+        unsigned long long walks[4] = {};
+        if (hipMemcpyFromSymbol(walks, HIP_SYMBOL(g_walk_stats), sizeof walks) == hipSuccess)
+            std::fprintf(stderr, "[k_paths]   walks begun (all launches so far): %llu, culling not allowed %llu, ray not tame %llu\n", walks[2], walks[0], walks[1]);
         unsigned long long scan[4] = {};
         if (hipMemcpyFromSymbol(scan, HIP_SYMBOL(g_scan_stats), sizeof scan) == hipSuccess && scan[3])
             std::fprintf(stderr, "[k_paths]   scan: %.0f clocks for the boxes, %.0f for the exact tests, %.2f trips of exact tests per scan\n",
