@@ -189,7 +189,9 @@ __device__ __forceinline__ void lds_reads_done() {
 
 // perlin.rs:52-85 + 100-122.  Tables may live in LDS (IN_LDS: the gradient vectors of four corners
 // are then fetched as twelve single reads, one wait) or in global memory.
-template <bool IN_LDS>
+// LEAN: the gradient vectors are fetched two corners at a time instead of four (twelve registers fewer,
+// twice the waits).
+template <bool IN_LDS, bool LEAN = false>
 __device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, const int32_t* __restrict__ perm_x,
                                                const int32_t* __restrict__ perm_y, const int32_t* __restrict__ perm_z,
                                                V3 p) {
@@ -204,7 +206,7 @@ __device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, 
     for (int di = 0; di < 2; ++di) {
         const int32_t px = perm_x[(int32_t)((uint32_t)i + (uint32_t)di) & 255];
         double gv[2][2][3];
-        if (IN_LDS) {
+        if (IN_LDS && !LEAN) {
 #pragma unroll
             for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
@@ -221,6 +223,17 @@ __device__ __forceinline__ double perlin_noise(const double* __restrict__ vecs, 
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
             const int32_t py = perm_y[(int32_t)((uint32_t)j + (uint32_t)dj) & 255];
+            if (IN_LDS && LEAN) {
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) {
+                    const int32_t pz = perm_z[(int32_t)((uint32_t)k + (uint32_t)dk) & 255];
+                    const uint32_t at = (uint32_t)(size_t)vecs + 24u * (uint32_t)(px ^ py ^ pz);
+                    gv[dj][dk][0] = lds_read_single_f64<0>(at);
+                    gv[dj][dk][1] = lds_read_single_f64<8>(at);
+                    gv[dj][dk][2] = lds_read_single_f64<16>(at);
+                }
+                lds_reads_done();
+            }
 #pragma unroll
             for (int dk = 0; dk < 2; ++dk) {
                 const int32_t pz = perm_z[(int32_t)((uint32_t)k + (uint32_t)dk) & 255];
@@ -255,6 +268,62 @@ __device__ __forceinline__ double perlin_turbulence(const double* __restrict__ v
         current_p = current_p * 2.0;
     }
     return fabs(accumulator);
+}
+
+// The same through generic pointers (LDS or global memory) and behind a call: for a kernel that meets
+// turbulence one lane at a time only in rare cases (perlin_turbulence_wave serves the usual ones) and
+// should not carry the inlined code's registers for them.
+__device__ __noinline__ double perlin_turbulence_rare(const mirt_perlin* pl, double x, double y, double z) {
+    return perlin_turbulence<false>(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, v3(x, y, z), 7);
+}
+
+// perlin_turbulence(p, 7) for the lanes of a wave that `want` it, computed by the WHOLE wave: the seven
+// octaves of one point are independent until they are summed, so eight lanes take one point -- lane j of
+// the group evaluates octave j (p * 2^j and the weight 2^-j are exact, as the repeated doubling and
+// halving of perlin.rs:45-47 are), the eighth idles -- and the point's owner adds the seven terms in
+// order, which is the sum the loop of perlin.rs:43-48 forms: same operations, same bits.  Eight points
+// per pass; a shading trip that holds a handful of noise hits pays one pass of one octave instead of
+// seven octaves run for those few lanes while the others look on.
+// Must be called by all 64 lanes of the wave together.
+//   want      this lane needs the turbulence at p, from table `table` of `lds_tables` (staged in LDS)
+//   points    32 x 8 bytes of LDS owned by this wave (p and the table of the pass's eight points)
+//   terms     64 x 8 bytes of LDS owned by this wave
+constexpr int TURBULENCE_POINTS = 8;
+__device__ __forceinline__ double perlin_turbulence_wave(bool want, const V3& p, uint32_t table, const mirt_perlin* lds_tables,
+                                                         unsigned long long* points, double* terms) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t group = lane >> 3, octave = lane & 7u;
+    double result = 0.0;
+    bool pending = want;
+    for (;;) {
+        const unsigned long long waiting = __builtin_amdgcn_ballot_w64(pending);
+        if (waiting == 0ull) break;
+        const uint32_t n = min((uint32_t)__popcll(waiting), (uint32_t)TURBULENCE_POINTS);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(waiting >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)waiting, 0u));
+        const bool mine = pending && rank < (uint32_t)TURBULENCE_POINTS;
+        if (mine) {
+            points[4 * rank + 0] = __builtin_bit_cast(unsigned long long, p.x);
+            points[4 * rank + 1] = __builtin_bit_cast(unsigned long long, p.y);
+            points[4 * rank + 2] = __builtin_bit_cast(unsigned long long, p.z);
+            points[4 * rank + 3] = table;
+        }
+        if (group < n && octave < 7u) {
+            const double up = __hiloint2double((int)((1023u + octave) << 20), 0);    // 2^octave
+            const double down = __hiloint2double((int)((1023u - octave) << 20), 0);  // 2^-octave
+            const V3 q = v3(__builtin_bit_cast(double, points[4 * group + 0]) * up, __builtin_bit_cast(double, points[4 * group + 1]) * up,
+                            __builtin_bit_cast(double, points[4 * group + 2]) * up);
+            const mirt_perlin* pl = lds_tables + (uint32_t)points[4 * group + 3];
+            terms[lane] = down * perlin_noise<true, true>(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, q);
+        }
+        if (mine) {
+            double accumulator = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) accumulator += terms[8 * rank + j];
+            result = fabs(accumulator);
+            pending = false;
+        }
+    }
+    return result;
 }
 
 // ---------------------------------------------------------------------- textures
@@ -297,9 +366,14 @@ enum TextureLevel : int { TEXTURES_CONSTANT = 0, TEXTURES_CHECKER = 1, TEXTURES_
 // `lds_tables` = the scene's first `n_staged` Perlin tables as the shade kernel staged them
 // in LDS (null / 0 when it staged none); other tables are read from global memory.
 // A texture of a kind above LEVEL evaluates to black: the host picks LEVEL from the scene.
-template <int LEVEL>
+// have_turbulence: `turbulence` is perlin_turbulence(h.p, 7) from the table of texture `tex` itself, which
+// is a noise texture (the caller had the wave compute it, perlin_turbulence_wave).
+// NOISE_INLINE: turbulence that is not known is evaluated inline (a kernel whose waves hold one class of
+// hits each); otherwise behind a call.
+template <int LEVEL, bool NOISE_INLINE = true>
 __device__ __forceinline__ V3 texture_value(const DScene& sc, const mirt_texture* textures, uint32_t tex, const Surface& h,
-                                            const mirt_perlin* lds_tables, uint32_t n_staged) {
+                                            const mirt_perlin* lds_tables, uint32_t n_staged, bool have_turbulence = false,
+                                            double turbulence_known = 0.0) {
     for (int guard = 0; guard < 64; ++guard) {
         const mirt_texture* t = textures + tex;
         const uint32_t kind = t->kind;
@@ -310,13 +384,18 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, const mirt_texture
         }
         if (LEVEL >= TEXTURES_ALL && kind == MIRT_TEX_NOISE) {  // texture.rs:82-87
             double turb;
-            if (t->perlin < n_staged) {
+            if (have_turbulence) {
+                turb = turbulence_known;
+            } else if (!NOISE_INLINE) {
+                turb = perlin_turbulence_rare(t->perlin < n_staged ? lds_tables + t->perlin : sc.perlins + t->perlin, h.p.x, h.p.y, h.p.z);
+            } else if (t->perlin < n_staged) {
                 const mirt_perlin* pl = lds_tables + t->perlin;
                 turb = perlin_turbulence<true>(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
             } else {
                 const mirt_perlin* __restrict__ pl = sc.perlins + t->perlin;
                 turb = perlin_turbulence<false>(&pl->vecs[0][0], pl->perm_x, pl->perm_y, pl->perm_z, h.p, 7);
             }
+            have_turbulence = false;
             const double turbulence = t->scale * h.p.z + 10.0 * turb;
             const double c = (1.0 * 0.5) * (1.0 + checker_sin(turbulence));
             return v3(c, c, c);

@@ -99,10 +99,6 @@ __device__ __forceinline__ void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);  // nothing that reads the values may be hoisted above the wait
 }
 
-#ifdef MIRT_PATHS_STATS
-// development build: walks begun without culling allowed, with a ray that is not tame, and in all
-__device__ unsigned long long g_walk_stats[4];
-#endif
 enum TraverseStat : int {
     STAT_OUTER_ITERS = 0,  // trips of the outer loop, per wave
     STAT_NODE_ITERS,       // wave-level node visits (trips of the inner loop)
@@ -449,11 +445,6 @@ struct RayWalk {
                               r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z;
         if (QNODES) cull.set_q(r, may_cull, sc.qgrid);
         else cull.set(r, may_cull);
-#ifdef MIRT_PATHS_STATS
-        if (!may_cull) atomicAdd(&g_walk_stats[0], 1ull);
-        if (!cull.tame) atomicAdd(&g_walk_stats[1], 1ull);
-        atomicAdd(&g_walk_stats[2], 1ull);
-#endif
         careful = false;
         weird = false;
         if (ODDITIES) {

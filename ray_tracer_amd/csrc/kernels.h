@@ -438,11 +438,11 @@ struct ShadeResult {
 
 // cls: shade class of the hit shape (SHADE_MISS: none).  `last`: this is the deepest bounce
 // allowed; what would be scattered is multiplied by color(.., 0) = 0 (renderer.rs:99-101).
-template <int TEXTURES>
+template <int TEXTURES, bool NOISE_INLINE = true>
 __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls, const RayD& r, double hit_t, uint32_t hit_ref,
                                                   uint32_t tk, const ShapeRec* rec, const mirt_texture* textures, const V3& beta,
                                                   const V3& in_sphere, uint64_t stream, uint32_t bounce, bool last, const V3& background, const mirt_perlin* lds_tables, uint32_t n_staged,
-                                                  ShadeClock& clock) {
+                                                  ShadeClock& clock, bool have_turbulence = false, double turbulence = 0.0) {
     ShadeResult out;
     out.alive = false;
     out.value = v3(0.0, 0.0, 0.0);
@@ -458,7 +458,7 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
     const uint32_t texture = rec->texture;
     if (cls == SHADE_LIGHT) {
         // material.rs:144-152: no scatter, emit = texture value
-        out.value = beta * (texture == NO_TEXTURE ? color : texture_value<TEXTURES>(sc, textures, texture, h, lds_tables, n_staged));
+        out.value = beta * (texture == NO_TEXTURE ? color : texture_value<TEXTURES, NOISE_INLINE>(sc, textures, texture, h, lds_tables, n_staged));
         return out;
     }
     if (last) return out;
@@ -496,7 +496,9 @@ __device__ __forceinline__ ShadeResult shade_path(const DScene& sc, uint32_t cls
     } else {  // the lambertian classes, material.rs:51-59
         const V3 target = h.p + h.normal + in_sphere;
         dir = target - h.p;
-        attenuation = cls == SHADE_LAMBERTIAN_CONSTANT ? color : texture_value<TEXTURES>(sc, textures, texture, h, lds_tables, n_staged);
+        attenuation = cls == SHADE_LAMBERTIAN_CONSTANT ? color
+                                                        : texture_value<TEXTURES, NOISE_INLINE>(sc, textures, texture, h, lds_tables, n_staged,
+                                                                                  have_turbulence && cls == SHADE_LAMBERTIAN_NOISE, turbulence);
         clock.mark(6);
     }
     if (scattered) {
@@ -676,6 +678,10 @@ constexpr uint32_t PATHS_TUNING_SCAN = 1u | (1u << 8) | (16u << 16) | (3u << 30)
 #ifndef MIRT_PARK_BIG
 #define MIRT_PARK_BIG 2
 #endif
+// The turbulence of a shading trip's noise-texture hits computed by the whole wave (perlin_turbulence_wave)
+#ifndef MIRT_TURBULENCE_WAVE
+#define MIRT_TURBULENCE_WAVE 1
+#endif
 // ... and with the nodes in LDS as QNodes and the records in global memory
 #ifndef MIRT_PARK_QNODES
 #define MIRT_PARK_QNODES 4
@@ -725,6 +731,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     // the textures shading can meet (one checker and its two colours, say), in LDS when they are few
     __shared__ mirt_texture s_textures[TEXTURES > TEXTURES_CONSTANT ? TEXTURES_STAGED : 1];
     __shared__ unsigned long long s_scratch[PATHS_BLOCK / 64][IN_SPHERE_SCRATCH];
+    __shared__ double s_turbulence[HAS_NOISE ? PATHS_BLOCK / 64 : 1][HAS_NOISE ? 64 : 1];  // perlin_turbulence_wave's terms
+    static_assert(IN_SPHERE_SCRATCH >= 4 * TURBULENCE_POINTS, "the in-sphere scratch doubles as perlin_turbulence_wave's points");
     const mirt_texture* textures = sc.shade_textures;
     if (TEXTURES > TEXTURES_CONSTANT && sc.n_shade_textures <= (uint32_t)TEXTURES_STAGED) {
         const uint32_t words = sc.n_shade_textures * (uint32_t)(sizeof(mirt_texture) / 4);
@@ -895,6 +903,22 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             const bool shading = have && walk.finished();
             const bool last = bounce + 1 == rp.max_depth;
             const uint32_t cls_now = walk.best.prim >= 0 ? ((uint32_t)walk.best.side >> walk.CLASS_SHIFT) & 7u : (uint32_t)SHADE_MISS;
+            // the turbulence of the hits on noise textures (a lambertian whose texture IS a noise texture with
+            // its table staged: class SHADE_LAMBERTIAN_NOISE): the whole wave works on those, too
+            bool have_turbulence = false;
+            double turbulence = 0.0;
+            if (HAS_NOISE && MIRT_TURBULENCE_WAVE) {
+                uint32_t table = 0;
+                if (shading && !last && cls_now == SHADE_LAMBERTIAN_NOISE) {
+                    const ShapeRec* rec = RECS_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)walk.best.prim * SHAPE_LDS_BYTES)
+                                                      : sc.recs + walk.best.prim;
+                    table = textures[rec->texture].perlin;
+                    have_turbulence = table < n_staged;
+                }
+                if (vote(have_turbulence) != 0ull)
+                    turbulence = perlin_turbulence_wave(have_turbulence, walk.r.o + walk.best.t * walk.r.d, table, lds_tables, s_scratch[tid >> 6],
+                                                        s_turbulence[tid >> 6]);
+            }
             const V3 in_sphere = random_in_unit_sphere_wave(shading && wants_in_sphere(cls_now, last), PathRng{stream, bounce + 1u, 0u},
                                                             s_scratch[tid >> 6]);
             extra_segments += (uint32_t)__popcll(vote(shading && bounce != bounce0));
@@ -908,8 +932,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                     hit_ref = (uint32_t)h.prim | (((uint32_t)h.side & walk.SIDE_MASK) << HIT_SIDE_SHIFT);
                     rec = RECS_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)h.prim * SHAPE_LDS_BYTES) : sc.recs + h.prim;
                 }
-                const ShadeResult s = shade_path<TEXTURES>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, in_sphere, stream, bounce, last, background, lds_tables, n_staged,
-                                                           shade_clock);
+                const ShadeResult s = shade_path<TEXTURES, !MIRT_TURBULENCE_WAVE>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, in_sphere, stream, bounce, last, background,
+                                                                                  lds_tables, n_staged, shade_clock, have_turbulence, turbulence);
                 // (the store comes last: whatever the next instructions wait for in memory, they would
                 // wait for it too)
                 if (s.alive) {

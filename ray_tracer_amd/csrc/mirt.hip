@@ -787,6 +787,9 @@ int blocks_per_cu(K kernel, int fallback) {
     return std::min(n, 8);
 }
 
+// The one workgroup per CU of the path kernel may use this much of the CU's 160 KB of LDS, static arrays included.
+constexpr size_t PATHS_LDS_BUDGET = 158 * 1024;
+
 // The path kernel's launch shape for one scene.
 struct PathsPlan {
     bool stack16 = true;
@@ -821,12 +824,13 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
     const size_t nodes = trav_nodes_bytes(scene->d.n_nodes), recs = (size_t)scene->d.n_shapes * SHAPE_LDS_BYTES;
     const size_t fixed = (textures >= TEXTURES_ALL ? sizeof(mirt_perlin) * PERLIN_STAGED : 0) +
                          (textures > TEXTURES_CONSTANT ? sizeof(mirt_texture) * TEXTURES_STAGED : 0) +
-                         sizeof(unsigned long long) * IN_SPHERE_SCRATCH * (p.block / 64);
+                         sizeof(unsigned long long) * IN_SPHERE_SCRATCH * (p.block / 64) +
+                         (textures >= TEXTURES_ALL ? sizeof(double) * 64 * (p.block / 64) : 0);
     const size_t stack = trav_stack_bytes(p.levels, p.stack16 ? 2 : 4, p.block);
     // ONE workgroup per CU, as many waves as the registers allow, sharing one copy of the tree: all
     // of it and the shapes' records if they fit, else as many nodes from the top as do
     // (REF16_MAX_SHAPES: the kernel with the tree in LDS parks shapes as 16-bit references)
-    p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && scene->d.n_shapes <= REF16_MAX_SHAPES && stack + nodes + recs + fixed <= TRAV_LDS_BUDGET;
+    p.tree_in_lds = scene->d.n_nodes > 0 && p.stack16 && scene->d.n_shapes <= REF16_MAX_SHAPES && stack + nodes + recs + fixed <= PATHS_LDS_BUDGET;
     // development aid: MIRT_SCAN_MAX overrides the largest scene rendered without a tree
     static const uint32_t scan_max = [] {
         const char* s = std::getenv("MIRT_SCAN_MAX");
@@ -844,7 +848,7 @@ hipError_t plan_paths(const mirt_scene* scene, PathsPlan* out) {
         p.lds_bytes = stack + nodes + recs;
         p.kernel = paths_kernel_for<uint16_t, TREE_LDS>(textures);
     } else {
-        const size_t room = TRAV_LDS_BUDGET > stack + fixed ? TRAV_LDS_BUDGET - stack - fixed : 0;
+        const size_t room = PATHS_LDS_BUDGET > stack + fixed ? PATHS_LDS_BUDGET - stack - fixed : 0;
         // development aid: MIRT_QNODES=0 keeps QNodes out, =2 prefers them to 56-byte nodes that would fit too
         static const int qnodes_mode = [] {
             const char* s = std::getenv("MIRT_QNODES");
@@ -1188,9 +1192,6 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         const char* parts[8] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "next ray / store"};
         for (int k = 0; k < 8; ++k)
             std::fprintf(stderr, "[k_paths]   shade: %-20s %5.1f %% of wave clocks\n", parts[k], 100.0 * (double)segments[2 + 13 + k] / total);
-        unsigned long long walks[4] = {};
-        if (hipMemcpyFromSymbol(walks, HIP_SYMBOL(g_walk_stats), sizeof walks) == hipSuccess)
-            std::fprintf(stderr, "[k_paths]   walks begun (all launches so far): %llu, culling not allowed %llu, ray not tame %llu\n", walks[2], walks[0], walks[1]);
         unsigned long long scan[4] = {};
         if (hipMemcpyFromSymbol(scan, HIP_SYMBOL(g_scan_stats), sizeof scan) == hipSuccess && scan[3])
             std::fprintf(stderr, "[k_paths]   scan: %.0f clocks for the boxes, %.0f for the exact tests, %.2f trips of exact tests per scan\n",
