@@ -11,18 +11,27 @@ it, or from a plain shell, in which case this script starts the N ranks itself -
 frame is split by interleaved rows across ranks (no data-path collective; rank 0 gathers
 the rendered rows), or with --split sample every rank renders all pixels for its share of
 the samples and the f64 accumulation images are summed with one RCCL reduce.  Scaling is
-weak by default: the same frame at N times the samples per pixel, so that every GPU
-renders as many samples as the one GPU of N = 1 does (--scaling strong shares out the
-configuration's own 500).  --single-process renders on the N devices from one process
-through mirt_render_multi instead; --backend gloo lets ranks share a GPU (a rehearsal).
+strong by default: the configuration's own frame and samples per pixel (BASELINE.json's
+1200x800 at 500 spp) shared out over the N GPUs, which is what `value` measures at every N;
+with N > 1 the same run then also times the weak case (the same frame at N times the
+samples per pixel, every GPU rendering as many samples as the one GPU of N = 1) and
+reports it under `weak_scaling` (--scaling weak makes that one `value` instead).
+--single-process renders on the N devices from one process through mirt_render_multi
+instead; --backend gloo lets ranks share a GPU (a rehearsal).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM with
-the bytes a queue-per-bounce pipeline moves for the same work (272 per path segment + 24
-per sample, `roofline.bytes_per_unit`): the path kernel (whole paths in registers, 24 bytes of
-radiance out per sample) in the default mode, the closest-hit kernel of the per-bounce
-pipeline with --handover -1.  Neither is bound by HBM: the path kernel saturates the vector
-ALU's issue slots (`roofline.valu_issue_busy`, measured), and `roofline.valu_f64` prices the
-reference traversal of the same rays against the f64 vector ALU.
+Rank 0 prints ONE JSON line.  `roofline` names what limits the dominant kernel.  For the
+path kernel (default mode: whole paths in registers, 24 bytes of radiance out per sample)
+that is the issue of vector instructions: `roofline.frac` = share of the SIMDs' cycles in
+which a vector instruction issues x lanes active in it / 64, from the SQ counters of this
+configuration committed under profiles/ (`counters_stale` says when they were collected
+with another build of the library than the one loaded: mirt_build_id).  The figure the
+survey defined -- the bytes a queue-per-bounce pipeline moves for the same work, 272 per path
+segment + 24 per sample, per second of this kernel over 8 TB/s -- is kept as
+`roofline.pipeline_equivalent` (a work-equivalent: the kernel moves none of those bytes, and
+it exceeds 1 on the Cornell box), the HBM traffic the kernel really has as `roofline.traffic`
+/ `hbm_frac_measured`, and `roofline.valu_f64` prices the reference traversal of the same
+rays against the f64 vector ALU.  With --handover -1 the dominant kernel is the closest-hit
+kernel of the per-bounce pipeline, priced against HBM with its queue traffic.
 `cpu_baseline` times the CPU oracle (a C++ restatement of the reference algorithm,
 not the reference itself: no Rust toolchain exists here) on a bounded sample of the
 same workload on the host cores of the same box.
@@ -64,9 +73,10 @@ def parse_args():
                          "bounce below bounce N, -1 = launches per bounce throughout, -2 = probe")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work to spend on the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak (default) = the same frame at N times the samples per pixel, so every GPU renders as many "
-                         "samples as the one GPU of N = 1; strong = the configuration's own samples per pixel shared out")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (default) = the configuration's own frame and samples per pixel shared out (the weak case is "
+                         "timed too and reported as weak_scaling); weak = the same frame at N times the samples per pixel, so "
+                         "every GPU renders as many samples as the one GPU of N = 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collectives between the ranks: nccl (RCCL over xGMI, one GPU per rank) or gloo (host memory; ranks "
                          "may then share a GPU: rank r uses device r mod the number of devices -- a rehearsal on a smaller box)")
@@ -146,6 +156,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from ray_tracer_amd import _abi as abi
     from ray_tracer_amd import api, configs, distributed
 
     if not torch.cuda.is_available() or api.device_count() < 1:
@@ -173,6 +184,8 @@ def main():
     if n_ranks > 1 and args.scaling == "weak":
         cfg = cfg.scaled(cfg.width, cfg.height, cfg.spp * n_ranks)
     W, H, spp = cfg.width, cfg.height, cfg.spp
+    # the other scaling's sample count, timed after the main loop when the main loop is the strong case
+    spp_weak = spp_one_gpu * n_ranks if (n_ranks > 1 and args.scaling == "strong") else 0
     if args.split == "sample" and n_ranks > 1 and spp < n_ranks:
         raise SystemExit(f"--split sample needs at least one sample per rank: spp {spp} < {n_ranks} ranks")
     world = cfg.world()
@@ -219,7 +232,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step():
+    def step(spp=spp):
         if len(rank_scenes) > 1:
             _, sts = api.render_world_multi(cfg.background, rank_scenes, cam, W, H, spp, split=args.split, paths_per_pass=args.paths_per_pass,
                                             out=out, return_stats=True, handover=(args.handover, 0))
@@ -267,6 +280,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    weak = None
+    if spp_weak:
+        # the weak case of the same run: the same frame at N times the samples per pixel, same bracket
+        weak_steps = max(1, min(args.steps, 3))
+        step(spp_weak)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(weak_steps):
+            step(spp_weak)
+        barrier()
+        weak_elapsed = time.perf_counter() - t0
+        if world_size > 1:
+            t = torch.tensor([weak_elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            weak_elapsed = float(t.item())
+        weak = {"value": float(W) * H * spp_weak * weak_steps / weak_elapsed / 1e6, "unit": "Msamples/s", "spp": spp_weak,
+                "steps": weak_steps, "warmup": 1, "ms_per_step": weak_elapsed * 1e3 / weak_steps,
+                "note": "the same frame at n_gpus x the configuration's samples per pixel: every GPU renders as many samples as "
+                        "the one GPU of n_gpus = 1"}
 
     # sums over ranks of what each rank's library calls report
     keys = ("samples", "segments", "segments_paths", "launches_extend", "launches_paths", "ms_extend", "ms_shade", "ms_bin",
@@ -293,7 +325,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": args.scaling if n_ranks > 1 else "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (seeded scene generator, world seed 0x5EED0001, render seed 0x5EED0002)",
@@ -310,6 +342,7 @@ def main():
             },
             "handover": {"bounce": int(step_stats[-1]["handover_bounce"]),
                          "path_kernel_segments_frac": tot["segments_paths"] / max(1.0, tot["segments"])},
+            "library_build_id": abi.libmirt().mirt_build_id().decode(),
             "scene_upload_ms": scene_upload_ms,
             "library_first_call_ms": first_call_ms,
             "mrays_per_s": tot["segments"] / elapsed / 1e6,
@@ -322,36 +355,41 @@ def main():
             # registers instead of moving: the same figure prices the per-bounce pipeline below
             bytes_per_launch = (tot["segments_paths"] * PIPELINE_BYTES_PER_SEGMENT + samples * PIPELINE_BYTES_PER_SAMPLE) / launches
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            result["roofline"] = {
-                "bound": "hbm",
-                "kernel": "k_paths (whole paths, one per lane: camera ray, closest hit, shade, next bounce, in registers)",
+            pipeline = {
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
                 "bytes_per_unit": {"segment": PIPELINE_BYTES_PER_SEGMENT, "sample": PIPELINE_BYTES_PER_SAMPLE},
                 "units_per_launch": {"segments": tot["segments_paths"] / launches, "samples": samples / launches},
+                "note": "a work-equivalent, not a utilisation: the bytes a queue-per-bounce pipeline moves through HBM for these "
+                        "segments (ray 56 + hit 16 + path state 88 in, 88 out + two queue indices 8 = 272 B per segment, 24 B "
+                        "per sample) per second of this kernel, which keeps all of it in registers",
+            }
+            roof = {
+                "bound": "valu_issue",
+                "kernel": "k_paths (whole paths, one per lane: camera ray, closest hit, shade, next bounce, in registers)",
+                "achieved": None,
+                "peak": 1.0,
+                "unit": "share of the vector ALU's lane issue slots (SIMD cycles in which a vector instruction issues x lanes active / 64)",
+                "frac": None,
+                "traffic": None,
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
-                "note": "`achieved`/`frac` are a pipeline-equivalent figure, not a utilisation: the bytes a queue-per-bounce "
-                        "pipeline moves through HBM for these segments (ray 56 + hit 16 + path state 88 in, 88 out + two queue "
-                        "indices 8 = 272 B per segment, 24 B per sample) per second of this kernel, which keeps all of it in "
-                        "registers.  What the kernel really uses: `traffic` / `hbm_frac_measured` (HBM, measured) and "
-                        "`issue_frac` = valu_issue_busy x lanes / 64 (share of the vector ALU's lane slots doing work: the "
-                        "limiting resource)",
+                "pipeline_equivalent": pipeline,
+                "pipeline_equivalent_frac": pipeline["frac"],
             }
-            # Measured side of the same kernel, from the PMC passes of this workload committed under profiles/
-            # (separate rocprofv3 --pmc runs; per path, scaled to this run's paths per launch): HBM traffic
-            # (FETCH_SIZE, WRITE_SIZE) and how busy the vector ALU's issue slots are with how many lanes.
-            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_pmc_{args.config}.json") for tag in ("r02", "r01"))
+            result["roofline"] = roof
+            # The counters of this kernel on this workload come from the PMC passes committed under profiles/
+            # (separate rocprofv3 --pmc runs of one launch; per path, scaled to this run's paths per launch).
+            tags = ("r03", "r02", "r01")
+            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_pmc_{args.config}.json") for tag in tags)
                              if os.path.exists(q)), None)
             if pmc_path is None and args.config == "C2":
                 pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_paths.json")
             if pmc_path and os.path.exists(pmc_path):
                 with open(pmc_path) as f:
                     pmc = json.load(f)
-                roof = result["roofline"]
                 roof["traffic"] = pmc["hbm_bytes_per_path"] * samples / launches
                 roof["hbm_frac_measured"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 busy = pmc.get("valu_issue_busy_share_of_simd_cycles")
@@ -359,9 +397,10 @@ def main():
                 roof["valu_issue_busy"] = busy
                 roof["lanes_active_per_valu_instruction"] = lanes
                 if busy is not None and lanes is not None:
-                    roof["issue_frac"] = busy * lanes / 64.0
-                    roof["limiting_resource"] = "valu_issue"
-                roof["traffic_source"] = os.path.relpath(pmc_path, ROOT) + " (counters per path x paths per launch)"
+                    roof["achieved"] = roof["frac"] = busy * lanes / 64.0
+                roof["counters_source"] = os.path.relpath(pmc_path, ROOT) + " (counters of one launch, per path x this run's paths per launch)"
+                roof["counters_build_id"] = pmc.get("library_build_id")
+                roof["counters_stale"] = pmc.get("library_build_id") != result["library_build_id"]
         elif profile and tot["ms_extend"] > 0:
             launches = tot["launches_extend"]
             avg_ms = tot["ms_extend"] / launches
@@ -383,6 +422,8 @@ def main():
                 "pipeline_gbs": (tot["segments"] * PIPELINE_BYTES_PER_SEGMENT + samples * PIPELINE_BYTES_PER_SAMPLE)
                                 / elapsed / 1e9,
             }
+        if weak:
+            result["weak_scaling"] = weak
         if profile:
             result["kernel_ms"] = {k[3:]: tot[k] / world_size for k in keys if k.startswith("ms_")}
         if args.cpu_seconds > 0 and world_size == 1:

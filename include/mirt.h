@@ -259,6 +259,11 @@ typedef struct mirt_stats {
 /* Version of this ABI (bumped on any incompatible change). */
 uint32_t mirt_abi_version(void);
 
+/* Identifies the sources this library was built from: the first 16 hex digits of the SHA-256 of its kernel
+ * and header files (ray_tracer_amd/Makefile computes it).  No counterpart in the reference; measurement
+ * records (profiles/, bench.py) carry it so that counters are never read beside a different build's timings. */
+const char* mirt_build_id(void);
+
 /* Thread-local text for the last error on this thread ("" if none). */
 const char* mirt_last_error(void);
 

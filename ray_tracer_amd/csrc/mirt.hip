@@ -191,6 +191,11 @@ extern "C" {
 
 uint32_t mirt_abi_version(void) { return 1; }
 
+#ifndef MIRT_BUILD_ID
+#define MIRT_BUILD_ID "unknown"
+#endif
+const char* mirt_build_id(void) { return MIRT_BUILD_ID; }
+
 const char* mirt_last_error(void) { return tl_error.c_str(); }
 
 int mirt_device_count(void) {
