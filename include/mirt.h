@@ -325,8 +325,10 @@ void mirt_accum_free(double* d_accum, int device);
 int mirt_accum_read(const double* d_accum, uint32_t width, uint32_t height, int device, double* host);
 int mirt_accum_write(double* d_accum, uint32_t width, uint32_t height, int device, const double* host);
 
-/* mirt_render_accumulate for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+/* mirt_render_accumulate for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, processes whose memory is budgeted up front).  No counterpart in the
+ * reference.  It allocates nothing; it is NOT fit for HIP graph capture: it works on the null stream,
+ * synchronises it, copies a few words back to the host and queries the kernel's occupancy.
  * Same arguments, same sums in d_accum bit for bit; it calls no hipMalloc / hipFree: the radiance
  * records of a pass live in an array of MIRT_STATIC_PASS_PATHS records (+16 KB of counters) that every
  * device the library runs on holds from load until the process ends.  Limits: the pixels selected by
@@ -372,8 +374,9 @@ enum {
     MIRT_SPLIT_SAMPLE = 1
 };
 enum {
-    /* slices fetched with peer copies (one per xGMI link at a time) and added in rank order: the
-     * result does not depend on timing; scenes may share a device */
+    /* slices fetched with peer copies (peer access is queried and enabled per pair of devices; a pair
+     * without it is served through host memory) and added in rank order: the result does not depend
+     * on timing; scenes may share a device */
     MIRT_REDUCE_PEER = 0,
     /* ncclReduceScatter (f64, sum) of RCCL, loaded from librccl.so on first use; every scene must be
      * on a device of its own */
@@ -397,6 +400,10 @@ int mirt_render_multi(const mirt_scene* const* scenes, uint32_t n_scenes, const 
                       const double background[3], uint32_t width, uint32_t height, uint32_t spp,
                       uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
                       const mirt_multi_opts* multi, uint8_t* out_rgb, mirt_stats* stats);
+
+/* Frees the device memory mirt_render_multi's sample split keeps between calls (per rank: its f64 image,
+ * a staging area and the bytes of its slice).  No counterpart in the reference. */
+int mirt_multi_trim(void);
 
 /* Camera::ray (src/camera.rs:65-88) for sample `sample` of pixel `pixel`
  * (idx of renderer.rs:74-75) for n consecutive (pixel, sample) pairs starting

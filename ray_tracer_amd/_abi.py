@@ -161,6 +161,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_ME
 MIRT_SYMBOLS = {
     "mirt_abi_version": (C.c_uint32, []),
     "mirt_build_id": (C.c_char_p, []),
+    "mirt_multi_trim": (C.c_int, []),
     "mirt_last_error": (C.c_char_p, []),
     "mirt_device_count": (C.c_int, []),
     "mirt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),

@@ -161,7 +161,10 @@ static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 namespace {
 // In host code `scratch` is only a handle for hipGetSymbolAddress; kernels, memsets and copies
-// get the address it returns for the device that is current, kept here per device.
+// get the address it returns for the device that is current, kept here per device.  The address is
+// asked for by the first mirt_render_accumulate_static call on a device (nothing else is bound by
+// MAX_DEVICES); the array itself belongs to the code object and occupies every device the library's
+// kernels are loaded on, used or not.
 constexpr int MAX_DEVICES = 64;
 struct ScratchOfDevice {
     std::mutex setup;        // guards ptr
@@ -318,9 +321,6 @@ static int scene_create_body(const mirt_scene_desc* desc, int device, mirt_scene
     if ((rc = guard.enter(device)) != MIRT_OK) return rc;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-
-    void* scratch_ptr = nullptr;  // set-up for mirt_render_accumulate_static: this device's copy of the array
-    if ((rc = scratch_address(dev, &scratch_ptr)) != MIRT_OK) return rc;
 
     // ---- host-side flattening
     std::vector<DShape> shapes(desc->n_shapes);

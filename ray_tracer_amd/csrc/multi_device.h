@@ -12,9 +12,11 @@
 //                 image on its device; then every rank OWNS a contiguous slice of the pixels, sums
 //                 that slice of all ranks' images and resolves it to bytes (a reduce-scatter, then a
 //                 gather into the caller's buffer through the host copies the bytes need anyway).
-//                 The sum is either the library's own -- peer copies of the slices (every xGMI link
-//                 carries one slice at a time) added in rank order, so the bytes do not depend on
-//                 timing -- or RCCL's ncclReduceScatter (ring order; needs distinct devices).
+//                 The sum is either the library's own -- peer copies of the slices (peer access is asked
+//                 for and switched on per pair of devices; a pair without it goes through host memory),
+//                 added in rank order, so the bytes do not depend on timing -- or RCCL's
+//                 ncclReduceScatter (ring order; needs distinct devices).  The ranks' buffers are kept
+//                 between calls (mirt_multi_trim frees them).
 #pragma once
 
 #include <dlfcn.h>
@@ -102,6 +104,70 @@ int rccl_comms_for(const std::vector<int>& devices, std::vector<void*>* out) {
         it = g_rccl_comms.emplace(devices, comms).first;
     }
     *out = it->second;
+    return MIRT_OK;
+}
+
+// ---- what the sample split keeps between calls, per rank slot: the rank's f64 image (padded to n equal
+// slices), its staging area and the bytes of its slice.  Guarded by g_multi_mutex for the whole of a call's
+// sample split; mirt_multi_trim gives the memory back.
+struct MultiSlot {
+    int device = -1;
+    double* accum = nullptr;
+    size_t accum_values = 0;
+    double* staging = nullptr;
+    size_t staging_values = 0;
+    uint8_t* bytes = nullptr;
+    size_t bytes_size = 0;
+    // Call with `dev` current.
+    void drop() {
+        (void)hipFree(accum);
+        (void)hipFree(staging);
+        (void)hipFree(bytes);
+        accum = staging = nullptr;
+        bytes = nullptr;
+        accum_values = staging_values = bytes_size = 0;
+    }
+    int reserve(int dev, size_t want_accum, size_t want_staging, size_t want_bytes) {
+        if (device != dev && device >= 0) {
+            DeviceGuard g;
+            int e = g.enter(device);
+            if (e != MIRT_OK) return e;
+            drop();
+        }
+        device = dev;
+        auto grow = [](auto** p, size_t* have, size_t want) -> hipError_t {
+            if (*have >= want) return hipSuccess;
+            (void)hipFree(*p);
+            *p = nullptr;
+            *have = 0;
+            hipError_t e = hipMalloc((void**)p, want * sizeof(**p));
+            if (e == hipSuccess) *have = want;
+            return e;
+        };
+        HIP_TRY(grow(&accum, &accum_values, want_accum));
+        HIP_TRY(grow(&staging, &staging_values, want_staging));
+        HIP_TRY(grow(&bytes, &bytes_size, want_bytes));
+        return MIRT_OK;
+    }
+};
+std::mutex g_multi_mutex;
+MultiSlot g_multi_slots[mirt::MULTI_MAX_RANKS];
+
+// Can device `to` read device `from`'s memory directly?  Asked of the runtime and, if so, switched on (once
+// per pair and process; "already on" is as good).
+int peer_access(int to, int from, uint8_t* direct) {
+    int can = 0;
+    HIP_TRY(hipDeviceCanAccessPeer(&can, to, from));
+    *direct = 0;
+    if (!can) return MIRT_OK;
+    DeviceGuard g;
+    int e = g.enter(to);
+    if (e != MIRT_OK) return e;
+    const hipError_t h = hipDeviceEnablePeerAccess(from, 0);
+    if (h != hipSuccess && h != hipErrorPeerAccessAlreadyEnabled)
+        return fail(MIRT_ERR_HIP, "hipDeviceEnablePeerAccess(%d) on device %d failed: %s", from, to, hipGetErrorString(h));
+    (void)hipGetLastError();  // (the "already enabled" status is sticky)
+    *direct = 1;
     return MIRT_OK;
 }
 
@@ -197,31 +263,32 @@ static int render_multi_body(const mirt_scene* const* scenes, uint32_t n_scenes,
                 return fail(MIRT_ERR_UNSUPPORTED, "MIRT_REDUCE_RCCL needs every scene on a device of its own; use MIRT_REDUCE_PEER");
             if ((rc = rccl_comms_for(devices, &comms)) != MIRT_OK) return rc;
         }
-        // Device memory of all ranks is released by one place, whatever fails in between.
-        struct PerRank {
-            double* accum = nullptr;    // padded_values doubles on the rank's device
-            double* staging = nullptr;  // the other ranks' slices (PEER), or the reduced slice (RCCL)
-            uint8_t* bytes = nullptr;
-        };
-        std::vector<PerRank> mem(n);
-        auto release = [&] {
-            for (uint32_t r = 0; r < n; ++r) {
-                DeviceGuard g;
-                if (g.enter(devices[r]) != MIRT_OK) continue;
-                (void)hipFree(mem[r].accum);
-                (void)hipFree(mem[r].staging);
-                (void)hipFree(mem[r].bytes);
-            }
-        };
+        // The ranks' images, staging areas and byte buffers are kept between calls (g_multi_slots: 2x-2.9x the
+        // f64 image per rank at 3840x2160 would otherwise be allocated and freed inside what a caller times);
+        // calls that split by samples take turns.
+        std::lock_guard<std::mutex> turn(g_multi_mutex);
+        // Every device must be usable before any rank starts: a rank that cannot enter its device would
+        // leave the others waiting in the collective.
+        for (uint32_t r = 0; r < n; ++r) {
+            DeviceGuard g;
+            if ((rc = g.enter(devices[r])) != MIRT_OK) return rc;
+        }
+        // Which slices can travel device to device: peer access asked for and switched on per pair, once.
+        std::vector<uint8_t> direct((size_t)n * n, 1);
+        if (m.reduce == MIRT_REDUCE_PEER)
+            for (uint32_t r = 0; r < n; ++r)
+                for (uint32_t q = 0; q < n; ++q) {
+                    if (devices[q] == devices[r]) continue;
+                    if ((rc = peer_access(devices[r], devices[q], &direct[(size_t)r * n + q])) != MIRT_OK) return rc;
+                }
+        const size_t staging_values = m.reduce == MIRT_REDUCE_RCCL ? slice_values : slice_values * (n - 1);
         rc = run_ranks(n, [&](uint32_t r) -> int {
             DeviceGuard g;
             int e = g.enter(devices[r]);
             if (e != MIRT_OK) return e;
-            const size_t staging_values = m.reduce == MIRT_REDUCE_RCCL ? slice_values : slice_values * (n - 1);
-            HIP_TRY(hipMalloc((void**)&mem[r].accum, padded_values * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&mem[r].staging, std::max<size_t>(staging_values, 1) * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&mem[r].bytes, slice_values));
-            HIP_TRY(hipMemsetAsync(mem[r].accum, 0, padded_values * sizeof(double), 0));
+            MultiSlot& mem = g_multi_slots[r];
+            if ((e = mem.reserve(devices[r], padded_values, std::max<size_t>(staging_values, 1), slice_values)) != MIRT_OK) return e;
+            HIP_TRY(hipMemsetAsync(mem.accum, 0, padded_values * sizeof(double), 0));
             const uint32_t lo = (uint32_t)((uint64_t)r * spp / n), hi = (uint32_t)((uint64_t)(r + 1) * spp / n);
             if (lo == hi) {  // fewer samples than ranks: this rank adds nothing but takes part in the sum
                 HIP_TRY(hipStreamSynchronize(0));
@@ -230,43 +297,64 @@ static int render_multi_body(const mirt_scene* const* scenes, uint32_t n_scenes,
             mirt_render_opts o = base;
             o.sample_begin = lo;
             o.sample_end = hi;
-            return render_accumulate_impl(scenes[r], camera, background, width, height, spp, max_depth, seed, &o, mem[r].accum, &rank_stats[r]);
+            return render_accumulate_impl(scenes[r], camera, background, width, height, spp, max_depth, seed, &o, mem.accum, &rank_stats[r]);
         });
         if (rc == MIRT_OK)
             rc = run_ranks(n, [&](uint32_t r) -> int {
                 DeviceGuard g;
                 int e = g.enter(devices[r]);
                 if (e != MIRT_OK) return e;
+                MultiSlot& mem = g_multi_slots[r];
                 const uint32_t first = std::min(r * slice_pixels, n_pixels), count = std::min(slice_pixels, n_pixels - first);
-                if (count == 0) return MIRT_OK;
                 const size_t off = (size_t)first * 3, values = (size_t)count * 3;
                 SlicePtrs src;
                 std::memset(&src, 0, sizeof src);
                 uint32_t n_src = n;
                 if (m.reduce == MIRT_REDUCE_RCCL) {
-                    const int ne = g_rccl.reduce_scatter(mem[r].accum, mem[r].staging, slice_values, Rccl::DOUBLE, Rccl::SUM, comms[r], 0);
+                    // (every rank calls the collective, also one whose slice of a tiny frame is empty: its peers wait in it)
+                    const int ne = g_rccl.reduce_scatter(mem.accum, mem.staging, slice_values, Rccl::DOUBLE, Rccl::SUM, comms[r], 0);
                     if (ne != 0) return fail(MIRT_ERR_HIP, "ncclReduceScatter failed: %s", g_rccl.error_string(ne));
-                    src.p[0] = mem[r].staging;
+                    src.p[0] = mem.staging;
                     n_src = 1;
+                    if (count == 0) {
+                        HIP_TRY(hipStreamSynchronize(0));
+                        return MIRT_OK;
+                    }
                 } else {
-                    double* stage = mem[r].staging;
+                    if (count == 0) return MIRT_OK;
+                    double* stage = mem.staging;
+                    std::vector<double> bounce;  // only for a pair of devices without peer access
                     for (uint32_t q = 0; q < n; ++q) {
+                        const double* theirs = g_multi_slots[q].accum + off;
                         if (devices[q] == devices[r]) {  // same device: read in place
-                            src.p[q] = mem[q].accum + off;
+                            src.p[q] = theirs;
                             continue;
                         }
-                        HIP_TRY(hipMemcpyPeerAsync(stage, devices[r], mem[q].accum + off, devices[q], values * sizeof(double), 0));
+                        if (direct[(size_t)r * n + q]) {
+                            HIP_TRY(hipMemcpyPeerAsync(stage, devices[r], theirs, devices[q], values * sizeof(double), 0));
+                        } else {
+                            // no peer access between the two: through host memory, said out loud
+                            bounce.resize(values);
+                            HIP_TRY(hipMemcpy(bounce.data(), theirs, values * sizeof(double), hipMemcpyDeviceToHost));
+                            HIP_TRY(hipMemcpy(stage, bounce.data(), values * sizeof(double), hipMemcpyHostToDevice));
+                        }
                         src.p[q] = stage;
                         stage += slice_values;
                     }
                 }
                 const int grid = (int)std::min<size_t>((values + BLOCK - 1) / BLOCK, 4096);
-                hipLaunchKernelGGL(k_sum_resolve, dim3(grid), dim3(BLOCK), 0, 0, src, n_src, (uint32_t)values, spp, mem[r].bytes);
+                hipLaunchKernelGGL(k_sum_resolve, dim3(grid), dim3(BLOCK), 0, 0, src, n_src, (uint32_t)values, spp, mem.bytes);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpy(out_rgb + off, mem[r].bytes, values, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(out_rgb + off, mem.bytes, values, hipMemcpyDeviceToHost));
                 return MIRT_OK;
             });
-        release();
+        if (rc != MIRT_OK) {
+            // whatever a failed rank left in flight must not outlive the call in buffers the next call reuses
+            for (uint32_t r = 0; r < n; ++r) {
+                DeviceGuard g;
+                if (g.enter(devices[r]) == MIRT_OK) (void)hipDeviceSynchronize();
+            }
+        }
     }
     if (rc != MIRT_OK) return rc;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -283,4 +371,19 @@ extern "C" int mirt_render_multi(const mirt_scene* const* scenes, uint32_t n_sce
                                  uint32_t max_depth, uint64_t seed, const mirt_render_opts* opts,
                                  const mirt_multi_opts* multi, uint8_t* out_rgb, mirt_stats* stats) {
     return no_throw([&] { return render_multi_body(scenes, n_scenes, camera, background, width, height, spp, max_depth, seed, opts, multi, out_rgb, stats); });
+}
+
+extern "C" int mirt_multi_trim(void) {
+    return no_throw([&]() -> int {
+        std::lock_guard<std::mutex> turn(g_multi_mutex);
+        for (MultiSlot& slot : g_multi_slots) {
+            if (slot.device < 0) continue;
+            DeviceGuard g;
+            int e = g.enter(slot.device);
+            if (e != MIRT_OK) return e;
+            slot.drop();
+            slot.device = -1;
+        }
+        return MIRT_OK;
+    });
 }

@@ -93,6 +93,7 @@ int decode_symbol(BitReader& br, const Huffman& h) {
 
 int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
 
+constexpr size_t MAX_PIXELS = (size_t)1 << 28;  // no frame header is believed beyond this
 const int ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
@@ -194,6 +195,8 @@ bool read_jpeg_baseline(const std::string& path, Image* out, std::string* why) {
             width = (seg[3] << 8) | seg[4];
             const int nc = seg[5];
             if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc || width <= 0 || height <= 0) return fail("one or three components expected");
+            // (a header can claim 65535 x 65535: the planes are sized from it before a single block is decoded)
+            if ((size_t)width * (size_t)height > MAX_PIXELS) return fail("more than 2^28 pixels");
             comps.resize((size_t)nc);
             for (int c = 0; c < nc; ++c) {
                 comps[c].id = seg[6 + 3 * c];
@@ -202,6 +205,8 @@ bool read_jpeg_baseline(const std::string& path, Image* out, std::string* why) {
                 comps[c].tq = seg[8 + 3 * c] & 3;
                 if (comps[c].h < 1 || comps[c].h > 2 || comps[c].v < 1 || comps[c].v > 2) return fail("sampling factors other than 1 and 2");
             }
+            // a scan of ONE component is not interleaved: one block per MCU whatever its sampling factors say (T.81 A.2.2)
+            if (nc == 1) comps[0].h = comps[0].v = 1;
         } else if (marker == 0xC2 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
             return fail("progressive, lossless and arithmetic-coded JPEG files are not read (baseline only)");
         } else if (marker == 0xDD) {
@@ -209,6 +214,7 @@ bool read_jpeg_baseline(const std::string& path, Image* out, std::string* why) {
             restart_interval = (seg[0] << 8) | seg[1];
         } else if (marker == 0xDA) {  // start of scan: the entropy-coded data follows
             if (comps.empty()) return fail("scan before frame header");
+            if (n < 1) return fail("truncated scan header");
             const int ns = seg[0];
             if (ns != (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail("one interleaved scan expected");
             for (int s = 0; s < ns; ++s) {

@@ -12,6 +12,9 @@
 //    image in FILE, written after every --checkpoint-every K samples per pixel (TRACER_CHECKPOINT_EVERY;
 //    default: once, at the end of the run), and a run that finds FILE goes on where it stops, with the
 //    seed it holds; --stop-after S (TRACER_STOP_AFTER) ends this run once S samples per pixel are done;
+//  * several GPUs: a frame rendered in one go is spread over all devices that are visible, by interleaved image
+//    rows; --devices N (TRACER_DEVICES) uses the first N, --split sample (TRACER_SPLIT) shares out the samples
+//    instead and sums the devices' images, --reduce rccl (TRACER_REDUCE) does that sum with RCCL;
 //  * --format p6 (TRACER_OUTPUT_FORMAT, or file_type = "p6" in [output]) writes binary PPM instead of the
 //    reference's ASCII P3 (ppm.rs:6-27), which stays the default.
 #include <chrono>
@@ -44,6 +47,12 @@ int main(int argc, char** argv) {
         ckpt.every = (size_t)std::strtoull(option(argc, argv, "--checkpoint-every", "TRACER_CHECKPOINT_EVERY").c_str(), nullptr, 0);
         ckpt.stop_after = (size_t)std::strtoull(option(argc, argv, "--stop-after", "TRACER_STOP_AFTER").c_str(), nullptr, 0);
         std::string format = option(argc, argv, "--format", "TRACER_OUTPUT_FORMAT");
+        const std::string split = option(argc, argv, "--split", "TRACER_SPLIT"), reduce = option(argc, argv, "--reduce", "TRACER_REDUCE");
+        if (!split.empty() && split != "tile" && split != "sample") throw std::runtime_error("unknown split " + split + " (tile, sample)");
+        if (!reduce.empty() && reduce != "peer" && reduce != "rccl") throw std::runtime_error("unknown reduce " + reduce + " (peer, rccl)");
+        rt::multi_device().devices = (int)std::strtol(option(argc, argv, "--devices", "TRACER_DEVICES").c_str(), nullptr, 0);
+        rt::multi_device().sample_split = split == "sample";
+        rt::multi_device().rccl = reduce == "rccl";
 
         const char* env_path = std::getenv("TRACER_CONFIG_PATH");
         const std::string config_path = env_path ? env_path : "./resources/tracer.toml";

@@ -164,9 +164,18 @@ struct FlatScene {
 };
 std::unique_ptr<FlatScene> flatten(const BoundingVolumeHierarchy& world);
 
-// src/renderer.rs:9-62: render_world through libmirt (mirt_scene_create + mirt_render).
-// render_parallel has no meaning on the device and is ignored.  Throws
-// std::runtime_error with mirt_last_error() on failure.
+// How render_world spreads a frame over the devices that are visible (the reference spreads it over the
+// threads of the process, renderer.rs:27-43).  Set once by the caller, before rendering.
+struct MultiDevice {
+    int devices = 0;            // how many devices to use; 0 = all that are visible
+    bool sample_split = false;  // false: interleaved image rows per device (no exchange); true: samples per device, summed
+    bool rccl = false;          // sample split: sum with ncclReduceScatter instead of peer copies
+};
+MultiDevice& multi_device();
+
+// src/renderer.rs:9-62: render_world through libmirt (mirt_scene_create + mirt_render, or one scene per
+// device + mirt_render_multi when several devices are visible).  render_parallel has no meaning on the
+// device and is ignored.  Throws std::runtime_error with mirt_last_error() on failure.
 std::vector<uint8_t> render_world(const Vec3& background, const BoundingVolumeHierarchy& world, const Camera& camera,
                                   size_t screen_width, size_t screen_height, size_t antialias_iterations,
                                   bool render_parallel, bool use_bounding_volume, uint64_t seed = 0x5EED0002ull,

@@ -79,7 +79,7 @@ def test_a_frame_in_instalments_equals_the_frame_in_one_go(tmp_path):
     # first run: instalments of 3 samples per pixel, stops after 4 (a process that ran out of time)
     stdout, s1, g1 = _run(cfg, "--checkpoint", str(ckpt), "--checkpoint-every", "3", "--stop-after", "4")
     assert "4 of 8 samples per pixel done (unfinished" in stdout and s1 == w * h * 4
-    assert ckpt.exists() and ckpt.stat().st_size == 56 + w * h * 3 * 8
+    assert ckpt.exists() and ckpt.stat().st_size == 64 + w * h * 3 * 8
     half = _read_p3(parts, w, h)  # the mean of the first 4 samples: an image already
     assert half.max() > 0
     # second run: finds the checkpoint, renders samples 4..8
@@ -95,6 +95,39 @@ def test_a_frame_in_instalments_equals_the_frame_in_one_go(tmp_path):
     env = dict(os.environ, TRACER_CONFIG_PATH=str(other), TRACER_SEED=str(SEED))
     r = subprocess.run([CLI, "--checkpoint", str(ckpt)], env=env, capture_output=True, text=True, timeout=110, cwd=ROOT)
     assert r.returncode == 101 and "another render" in r.stderr
+    # ... and so is one of the same frame, sample count and seed over another scene, camera or background
+    # (the header carries a hash of the flattened scene, the camera and the background)
+    cfg = _scaled_default_config(tmp_path, w, h, spp, parts)  # (the same file name: written again with this render's numbers)
+    for change in ({"background": (0.1, 0.2, 0.3)}, {"look_from": "x = 270.0"}, {"scene": "SimpleLight"}):
+        text = cfg.read_text()
+        env = dict(os.environ, TRACER_CONFIG_PATH=str(tmp_path / "changed.toml"), TRACER_SEED=str(SEED))
+        if "background" in change:
+            env["TRACER_BACKGROUND"] = ",".join(str(x) for x in change["background"])
+        if "look_from" in change:
+            assert "x = 278.0" in text
+            text = text.replace("x = 278.0", change["look_from"], 1)
+        if "scene" in change:
+            text = text.replace('scene = "CornellBox"', f'scene = "{change["scene"]}"')
+        (tmp_path / "changed.toml").write_text(text)
+        r = subprocess.run([CLI, "--checkpoint", str(ckpt)], env=env, capture_output=True, text=True, timeout=110, cwd=ROOT)
+        assert r.returncode == 101 and "the scene, the camera or the background differ" in r.stderr, (change, r.stderr[-500:])
+    # the unchanged render still finds its checkpoint
+    stdout, s4, _ = _run(cfg, "--checkpoint", str(ckpt))
+    assert s4 == 0
+
+
+def test_cli_spreads_a_frame_over_the_visible_devices(tmp_path):
+    """With one GPU the flags are accepted and change nothing; with several, rows (or samples) are shared out
+    over them through mirt_render_multi and the frame is the one-device frame."""
+    w, h, spp = 60, 40, 6
+    one = tmp_path / "one.ppm"
+    _, samples, segments = _run(_scaled_default_config(tmp_path, w, h, spp, one), "--devices", "1")
+    ref = _read_p3(one, w, h)
+    out = tmp_path / "all.ppm"
+    _, s_all, g_all = _run(_scaled_default_config(tmp_path, w, h, spp, out))
+    assert (s_all, g_all) == (samples, segments) and np.array_equal(_read_p3(out, w, h), ref)
+    _, s_smp, g_smp = _run(_scaled_default_config(tmp_path, w, h, spp, out), "--split", "sample")
+    assert (s_smp, g_smp) == (samples, segments) and np.abs(_read_p3(out, w, h) - ref).max() <= 1
 
 
 def test_binary_ppm_holds_the_ascii_ppm_values(tmp_path):

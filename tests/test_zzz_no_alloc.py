@@ -38,6 +38,18 @@ def test_static_entry_point_matches_the_allocating_one(worlds):
         got, want, st_got, st_want = _both(scene, cfg.camera(w, h), cfg.background, w, h, spp)
         assert st_got["passes"] == 1 and st_got["segments"] == st_want["segments"]
         assert want.any() and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        # a warm call leaves the device's free memory where it was: nothing allocated, nothing freed and kept
+        import torch
+
+        cam = cfg.camera(w, h)
+        accum = torch.zeros(w * h * 3, dtype=torch.float64, device="cuda")
+        api.render_accumulate(scene, cam, cfg.background, w, h, spp, accum.data_ptr(), static=True)
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info()
+        api.render_accumulate(scene, cam, cfg.background, w, h, spp, accum.data_ptr(), static=True)
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after == free_before, (free_before, free_after)
         # a sample range and a tile split through the same entry point
         got, want, _, _ = _both(scene, cfg.camera(w, h), cfg.background, w, h, spp, sample_range=(2, 5), tiles=(w, 3, 1))
         assert want.any() and np.array_equal(got.view(np.uint64), want.view(np.uint64))
