@@ -81,6 +81,8 @@ extern "C" {
     pub fn mirt_device_count() -> c_int;
     pub fn mirt_scene_create(desc: *const MirtSceneDesc, device: c_int, out: *mut *mut MirtScene) -> c_int;
     pub fn mirt_scene_destroy(scene: *mut MirtScene);
+    pub fn mirt_build_id() -> *const c_char;
+    pub fn mirt_multi_trim() -> c_int;
     pub fn mirt_render(scene: *const MirtScene, camera: *const MirtCamera, background: *const f64, width: u32, height: u32,
                        spp: u32, max_depth: u32, seed: u64, opts: *const MirtRenderOpts, out_rgb: *mut u8,
                        stats: *mut MirtStats) -> c_int;

@@ -5,19 +5,55 @@
 use std::collections::HashMap;
 
 use image::GenericImageView;
-use rand::Rng;
 
 use crate::{
     bvh::{BVHMember, BoundingVolumeHierarchy},
     camera::Camera,
     ffi::*,
-    hittable::Shape,
+    hittable::{Rect, Shape},
     material::Material,
     texture::Texture,
     vec3::Vec3,
 };
 
 fn arr(v: &Vec3) -> [f64; 3] { [v[0], v[1], v[2]] }
+
+/// FNV-1a, 64 bits.
+fn fnv(bytes: &[u8]) -> u64 {
+    bytes.iter().fold(0xCBF2_9CE4_8422_2325u64, |h, b| (h ^ *b as u64).wrapping_mul(0x0000_0100_0000_01B3))
+}
+
+/// What makes two textures the same texture.  `Debug` holds every field of the constant, checker and noise
+/// textures, but `ImageTexture` prints the fixed word "ImageTexture" (texture.rs:100-104): an image is keyed
+/// by its content -- dimensions and a hash of its RGB8 pixels -- and a checker by its children's keys, since it
+/// may hold an image.
+fn texture_key(t: &Texture) -> String {
+    match t {
+        Texture::Image(i) => {
+            let (w, h) = i.image.dimensions();
+            format!("image:{}x{}:{:016x}", w, h, fnv(&image_rgb8(&i.image)))
+        }
+        Texture::Checker(c) => format!("checker({},{})", texture_key(&c.even), texture_key(&c.odd)),
+        other => format!("{:?}", other),
+    }
+}
+
+/// ... and two materials the same material (a lambertian or a light may hold an image).
+fn material_key(m: &Material) -> String {
+    match m {
+        Material::Lambertian(l) => format!("lambertian({})", texture_key(&l.albedo)),
+        Material::DiffuseLight(l) => format!("light({})", texture_key(&l.texture)),
+        other => format!("{:?}", other),
+    }
+}
+
+/// Tightly packed RGB8, row 0 = top: what `get_pixel` hands `ImageTexture::value` (texture.rs:118-121).
+fn image_rgb8(image: &image::DynamicImage) -> Vec<u8> {
+    let (w, h) = image.dimensions();
+    let mut rgb = Vec::with_capacity((w * h * 3) as usize);
+    for y in 0..h { for x in 0..w { let p = image.get_pixel(x, y); rgb.extend_from_slice(&[p[0], p[1], p[2]]); } }
+    rgb
+}
 
 /// Owns everything a `MirtSceneDesc` points into.
 #[derive(Default)]
@@ -30,14 +66,14 @@ pub struct FlatScene {
     pub images: Vec<MirtImage>,
     pub nodes: Vec<MirtBvhMember>,
     // the reference clones a material into every shape (hittable.rs:406-411) and a texture into every material:
-    // equal values are written once (keyed by their Debug text, which holds every field)
+    // equal values are written once (material_key / texture_key)
     material_ids: HashMap<String, u32>,
     texture_ids: HashMap<String, u32>,
 }
 
 impl FlatScene {
     fn texture(&mut self, t: &Texture) -> u32 {
-        let key = format!("{:?}", t);
+        let key = texture_key(t);
         if let Some(&id) = self.texture_ids.get(&key) { return id; }
         let mut out = MirtTexture::default();
         match t {
@@ -60,9 +96,7 @@ impl FlatScene {
                 out.kind = TEX_IMAGE;
                 out.image = self.pixels.len() as u32;
                 let (w, h) = i.image.dimensions();
-                let mut rgb = Vec::with_capacity((w * h * 3) as usize);
-                for y in 0..h { for x in 0..w { let p = i.image.get_pixel(x, y); rgb.extend_from_slice(&[p[0], p[1], p[2]]); } }  // texture.rs:118-121
-                self.pixels.push(rgb);
+                self.pixels.push(image_rgb8(&i.image));
                 self.images.push(MirtImage { width: w, height: h, rgb: std::ptr::null() });  // pointer set in desc()
             }
         }
@@ -73,7 +107,7 @@ impl FlatScene {
     }
 
     fn material(&mut self, m: &Material) -> u32 {
-        let key = format!("{:?}", m);
+        let key = material_key(m);
         if let Some(&id) = self.material_ids.get(&key) { return id; }
         let mut out = MirtMaterial::default();
         match m {
@@ -103,7 +137,12 @@ impl FlatScene {
                 // Cube::new (hittable.rs:403-420) builds its six rects from (min, max) and one material
                 out.kind = SHAPE_CUBE;
                 out.f[..3].copy_from_slice(&arr(&c.min)); out.f[3..6].copy_from_slice(&arr(&c.max));
-                out.material = self.material(c.side_material());  // accessor: the material of sides[0]
+                // every side holds a clone of the one material: read it from sides[0], which is always Rect::Xy
+                out.material = match &c.sides[0] {
+                    Rect::Xy(r) => self.material(&r.material),
+                    Rect::Xz(r) => self.material(&r.material),
+                    Rect::Yz(r) => self.material(&r.material),
+                };
             }
             Shape::MovingSphere(m) => {
                 out.kind = SHAPE_MOVING_SPHERE;
@@ -159,11 +198,12 @@ impl Camera {
     }
 }
 
-/// New body for `renderer::render_world` (renderer.rs:9-62): same signature, same `Vec<u8>` (W*H*3 bytes, top row
-/// first).  With more than one device visible the frame is tile-split over all of them.
-pub fn render_world<T: Rng>(background: &Vec3, world: &BoundingVolumeHierarchy, camera: &Camera, screen_width: usize,
-                            screen_height: usize, antialias_iterations: usize, _render_parallel: bool,
-                            use_bounding_volume: bool, rng: &mut T) -> Vec<u8> {
+/// New body for `renderer::render_world` (renderer.rs:9-62): the SAME signature, the same `Vec<u8>` (W*H*3
+/// bytes, top row first).  The sampler seed is drawn from entropy, as the reference seeds every worker
+/// (renderer.rs:30, 47).  With more than one device visible the frame is tile-split over all of them.
+pub fn render_world<'a>(background: &Vec3, world: &'a BoundingVolumeHierarchy, camera: &Camera, screen_width: usize,
+                        screen_height: usize, antialias_iterations: usize, _render_parallel: bool,
+                        use_bounding_volume: bool) -> Vec<u8> {
     let mut flat = world.flatten();
     let desc = flat.desc();
     let n_devices = unsafe { mirt_device_count() }.max(1) as usize;
@@ -175,7 +215,7 @@ pub fn render_world<T: Rng>(background: &Vec3, world: &BoundingVolumeHierarchy, 
     let opts = MirtRenderOpts::new(use_bounding_volume);
     let multi = MirtMultiOpts { struct_size: std::mem::size_of::<MirtMultiOpts>() as u32, split: SPLIT_TILE, ..Default::default() };
     let bg = arr(background);
-    let seed: u64 = rng.gen();  // the reference seeds every worker from entropy (renderer.rs:30, 47)
+    let seed: u64 = rand::random();
     let handles: Vec<*const MirtScene> = scenes.iter().map(|s| *s as *const MirtScene).collect();
     check(unsafe {
         mirt_render_multi(handles.as_ptr(), handles.len() as u32, &camera.to_ffi(), bg.as_ptr(), screen_width as u32,
