@@ -355,6 +355,42 @@ __device__ __forceinline__ double fclamp(double x, double lo, double hi) {
     return x;
 }
 
+// One entry of a texture table in registers.  The table is the scene's (global memory) or a kernel's copy in
+// LDS; the pointer says which at run time, and a load through such a pointer travels the long way round
+// (and waits for every memory operation in flight).  Here the pointer is asked once, and the entry is read
+// with the instructions of the memory it lies in.
+struct TextureEntry {
+    uint32_t kind, even, odd, perlin, image;
+    double color[3], scale;
+};
+template <int OFFSET>
+__device__ __forceinline__ uint2 lds_read_single_u32x2(uint32_t addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+static_assert(sizeof(mirt_texture) == 56 && offsetof(mirt_texture, color) == 24 && offsetof(mirt_texture, scale) == 48, "load_texture reads a mirt_texture by offsets");
+__device__ __forceinline__ TextureEntry load_texture(const mirt_texture* textures, uint32_t tex) {
+    TextureEntry e;
+    const mirt_texture* t = textures + tex;
+    if (__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)t)) {
+        const uint32_t at = (uint32_t)(size_t)t;
+        const uint2 a = lds_read_single_u32x2<0>(at), b = lds_read_single_u32x2<8>(at), c = lds_read_single_u32x2<16>(at);
+        e.color[0] = lds_read_single_f64<24>(at);
+        e.color[1] = lds_read_single_f64<32>(at);
+        e.color[2] = lds_read_single_f64<40>(at);
+        e.scale = lds_read_single_f64<48>(at);
+        lds_reads_done();
+        e.kind = a.x, e.even = a.y, e.odd = b.x, e.perlin = b.y, e.image = c.x;
+    } else {
+        const __attribute__((address_space(1))) mirt_texture* g = (const __attribute__((address_space(1))) mirt_texture*)t;
+        e.kind = g->kind, e.even = g->even, e.odd = g->odd, e.perlin = g->perlin, e.image = g->image;
+        e.color[0] = g->color[0], e.color[1] = g->color[1], e.color[2] = g->color[2];
+        e.scale = g->scale;
+    }
+    return e;
+}
+
 // The texture kinds a kernel is compiled for: every kind up to and including LEVEL in the
 // order below.  Each kind costs registers wherever textures are evaluated (measured for the
 // path kernel: constant 126 VGPRs, + checker 151, everything 251), so a scene that has no
@@ -375,7 +411,8 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, const mirt_texture
                                             const mirt_perlin* lds_tables, uint32_t n_staged, bool have_turbulence = false,
                                             double turbulence_known = 0.0) {
     for (int guard = 0; guard < 64; ++guard) {
-        const mirt_texture* t = textures + tex;
+        const TextureEntry entry = load_texture(textures, tex);
+        const TextureEntry* t = &entry;
         const uint32_t kind = t->kind;
         if (kind == MIRT_TEX_CONSTANT) return v3(t->color[0], t->color[1], t->color[2]);
         if (LEVEL >= TEXTURES_CHECKER && kind == MIRT_TEX_CHECKER) {  // texture.rs:45-54
@@ -412,7 +449,9 @@ __device__ __forceinline__ V3 texture_value(const DScene& sc, const mirt_texture
         if (i > im->width - 1) i = im->width - 1;
         if (j > im->height - 1) j = im->height - 1;
         const double color_scale = 1.0 / 255.0;
-        const uint8_t* __restrict__ px = im->rgb + 3 * ((size_t)j * im->width + i);
+        // (the pixels are global memory: said so, the three loads need not go by the generic path)
+        const __attribute__((address_space(1))) uint8_t* px =
+            (const __attribute__((address_space(1))) uint8_t*)(im->rgb + 3 * ((size_t)j * im->width + i));
         return v3((double)px[0] * color_scale, (double)px[1] * color_scale, (double)px[2] * color_scale);
     }
     return v3(0.0, 0.0, 0.0);

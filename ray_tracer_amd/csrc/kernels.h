@@ -405,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin(Paths P, RenderParams rp, uint32_
 // Development builds (MIRT_PATHS_STATS): wave clocks of the pieces of one shade trip.
 struct ShadeClock {
 #ifdef MIRT_PATHS_STATS
-    enum { N = 8 };
+    enum { N = 10 };
     unsigned long long clk[N] = {}, last = 0;
     __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); }
     __device__ __forceinline__ void mark(int k) {
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 if (shading && !last && cls_now == SHADE_LAMBERTIAN_NOISE) {
                     const ShapeRec* rec = RECS_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes + (uint32_t)walk.best.prim * SHAPE_LDS_BYTES)
                                                       : sc.recs + walk.best.prim;
-                    table = textures[rec->texture].perlin;
+                    table = load_texture(textures, rec->texture).perlin;
                     have_turbulence = table < n_staged;
                 }
                 if (vote(have_turbulence) != 0ull)
@@ -929,7 +929,10 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             if (shading) {
                 const HitRec h = walk.best;
                 uint32_t cls = SHADE_MISS, hit_ref = HIT_MISS, tk = 0;
-                const ShapeRec* rec = sc.recs;
+                // (a record in LDS is read with LDS instructions only if every value this pointer can take lies in LDS:
+                // mixed with a global address it becomes a generic pointer, whose loads travel the long way round
+                // and wait for every memory operation in flight)
+                const ShapeRec* rec = RECS_IN_LDS ? reinterpret_cast<const ShapeRec*>(lds.shapes) : sc.recs;
                 if (h.prim >= 0) {
                     cls = ((uint32_t)h.side >> walk.CLASS_SHIFT) & 7u;
                     tk = ((uint32_t)h.side >> walk.TK_SHIFT) & 7u;
@@ -938,6 +941,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 }
                 const ShadeResult s = shade_path<TEXTURES, !MIRT_TURBULENCE_WAVE>(sc, cls, walk.r, h.t, hit_ref, tk, rec, textures, beta, in_sphere, stream, bounce, last, background,
                                                                                   lds_tables, n_staged, shade_clock, have_turbulence, turbulence);
+                shade_clock.mark(7);
                 // (the store comes last: whatever the next instructions wait for in memory, they would
                 // wait for it too)
                 if (s.alive) {
@@ -949,13 +953,14 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                     ++bounce;
                     walk.begin(sc, r, rp.t_min, rp.t_max);
                 }
+                shade_clock.mark(8);
                 if (!s.alive) {
                     store_radiance(P, slot, s.value);
                     have = false;
                     walk.reset();
                 }
             }
-            shade_clock.mark(7);
+            shade_clock.mark(9);
             PS_STOP(PS_SHADE, n_finished);
             continue;
         }

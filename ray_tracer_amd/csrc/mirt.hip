@@ -1193,9 +1193,9 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
             std::fprintf(stderr, "[k_paths] %-6s %5.1f %% of wave clocks, %10.0f trips, %7.0f clocks per trip, %4.1f lanes per trip\n",
                          names[k], 100.0 * clk / total, trips, trips ? clk / trips : 0.0, trips ? lanes / trips : 0.0);
         }
-        std::fprintf(stderr, "[k_paths] other  %5.1f %%, %.0f trips of the outer loop\n", 100.0 * (total - sum) / total, (double)segments[2 + 13 + 8]);
-        const char* parts[8] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "next ray / store"};
-        for (int k = 0; k < 8; ++k)
+        std::fprintf(stderr, "[k_paths] other  %5.1f %%, %.0f trips of the outer loop\n", 100.0 * (total - sum) / total, (double)segments[2 + 13 + 10]);
+        const char* parts[10] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "result", "next ray", "store"};
+        for (int k = 0; k < 10; ++k)
             std::fprintf(stderr, "[k_paths]   shade: %-20s %5.1f %% of wave clocks\n", parts[k], 100.0 * (double)segments[2 + 13 + k] / total);
         unsigned long long scan[4] = {};
         if (hipMemcpyFromSymbol(scan, HIP_SYMBOL(g_scan_stats), sizeof scan) == hipSuccess && scan[3])
