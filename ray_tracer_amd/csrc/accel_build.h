@@ -618,7 +618,14 @@ inline QTree build_qtree(const BuiltTree& t, uint32_t n_shapes) {
                 hi[a] = std::fmax(hi[a], h);
             }
     for (int a = 0; a < 3; ++a) {
-        q.grid.center[a] = 0.5 * lo[a] + 0.5 * hi[a];
+        // A half resolves 2^-11 of a bound's distance from the centre: the centre goes where the leaves are (the
+        // median of their boxes' middles), not to the middle of the extremes, which one huge shape decides.
+        std::vector<double> middles;
+        for (const CNode& n : t.nodes)
+            for (int c = 0; c < 2; ++c)
+                if (n.child[c] & REF_LEAF) middles.push_back(0.5 * n.b[a][0][c] + 0.5 * n.b[a][1][c]);
+        std::nth_element(middles.begin(), middles.begin() + middles.size() / 2, middles.end());
+        q.grid.center[a] = middles.empty() ? 0.5 * lo[a] + 0.5 * hi[a] : middles[middles.size() / 2];
         const double half_extent = std::fmax(hi[a] - q.grid.center[a], q.grid.center[a] - lo[a]);
         // a power of two that brings the half extent to at most 2^14 grid units: far from both ends of a half's range
         int e = 0;
