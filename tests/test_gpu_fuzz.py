@@ -75,7 +75,9 @@ def _random_world(seed, n_shapes=(24, 90), planar=False):
 
 
 @pytest.mark.parametrize("seed,n_shapes,planar", [(s, (24, 90), False) for s in range(10)] + [(s, (1 + s % 5, 16), False) for s in range(8)] +
-                         [(s, (1 + s % 4, 11), True) for s in range(10)])
+                         [(s, (1 + s % 4, 11), True) for s in range(10)] +
+                         # thousands of shapes: the path kernel walks such a tree from LDS in its 28-byte form (bounds as halves)
+                         [(s, (2200, 3400), False) for s in range(2)])
 def test_random_worlds_render_and_intersect_like_the_oracle(seed, n_shapes, planar, oracle):
     """(planar: rects and cubes only -- such a world, when small, is rendered without a tree, cube faces as items of their own)"""
     built, eye, aperture, shutter = _random_world(seed, n_shapes, planar)
