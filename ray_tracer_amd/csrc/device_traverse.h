@@ -168,25 +168,28 @@ struct CullRay {
     }
     // The same constants for a tree whose bounds are halves in grid units (device_scene.h, QNode): the
     // bound g maps to t = g * (step * inv) + c with c = (center - o) * inv -+ E.  Against the exact
-    // (center + g * step - o) / d the computed t carries relative errors of at most 2^-22 (rounding d and
-    // center - o to f32, v_rcp_f32, the product, the FMA), proportional to |g * step * inv| <= half * |step * inv|
-    // or to |(center - o) * inv|: E = 2^-19 of their sum, eight times what is needed.  A ray whose terms
-    // are not all finite and of sane size is not culled at all (`tame` is the culling flag here): with
-    // every term finite no NaN arises and nothing rests on one being dropped.
+    // (center + g * step - o) / d the computed t carries relative errors of at most 6e-7 in all (2^-24 for
+    // rounding d to f32 and 2^-23 for v_rcp_f32 on both terms; 2^-24 each for rounding center - o, the product
+    // with inv and c -+ E; 2^-24 for the FMA; g itself and g * step are exact), proportional to
+    // |g * step * inv| <= half * |step * inv| or to |(center - o) * inv|: E = 2^-18 of their sum, six times
+    // what is needed.  A ray whose terms are not all finite, of sane size and in f32's normal range (step * inv
+    // must not underflow: the bound rests on its being exact) is not culled at all (`tame` is the culling flag
+    // here): with every term finite no NaN arises and nothing rests on one being dropped.
     __device__ __forceinline__ void set_q(const RayD& r, bool cull, const QGrid& grid) {
         const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
-        float size = 0.0f, inv_q[3], c[3], e[3];
+        float size = 0.0f, least = __builtin_inff(), inv_q[3], c[3], e[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float i32 = __builtin_amdgcn_rcpf((float)d[a]);
             const float p = (float)(grid.center[a] - o[a]) * i32;
             inv_q[a] = i32 * grid.step[a];
-            e[a] = (__builtin_fabsf(p) + __builtin_fabsf(inv_q[a]) * grid.half[a]) * 0x1.0p-19f;
+            e[a] = (__builtin_fabsf(p) + __builtin_fabsf(inv_q[a]) * grid.half[a]) * 0x1.0p-18f;
             size += __builtin_fabsf(i32) + __builtin_fabsf(p) + __builtin_fabsf(inv_q[a]) * grid.half[a];
+            least = fminf(least, __builtin_fabsf(inv_q[a]));
             c[a] = p;
             off[a] = i32 < 0.0f ? 16u : 0u;  // the rotation that brings the near bound of a QBox dword into its low half
         }
-        tame = cull && size < 1.0e18f;  // false for a NaN
+        tame = cull && size < 1.0e18f && least > 1.0e-30f;  // false for a NaN
         float far[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
