@@ -809,6 +809,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     unsigned long long ps_clk[PS_N] = {}, ps_trips[PS_N] = {}, ps_lanes[PS_N] = {};
     ShadeClock shade_clock;
     unsigned long long ps_outer = 0;
+    unsigned long long ps_idle[3] = {};  // in node trips: lanes holding a hit that waits for shading, empty lanes, lanes that can only test shapes
     const unsigned long long ps_begin = __builtin_amdgcn_s_memtime();
 #define PS_START() const unsigned long long ps_t0 = __builtin_amdgcn_s_memtime()
 #define PS_STOP(k, lanes)                                                   \
@@ -983,6 +984,11 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             bool wants = walk.wants_node();
             do {
                 PS_START();
+#ifdef MIRT_PATHS_STATS
+                ps_idle[0] += __popcll(vote(have && walk.finished() && walk.best.prim >= 0));
+                ps_idle[1] += __popcll(vote(!have || (walk.finished() && walk.best.prim < 0)));
+                ps_idle[2] += __popcll(vote(have && !walk.finished() && !walk.wants_node()));
+#endif
                 if (wants) walk.node_step(sc, lds, stack, tid, rp.t_min);
                 // (a second visit for the lanes that still want one before the wave is asked again: +1.3 % on the
                 // 3 507-shape scene, whose walks are long; nothing on trees that are in LDS as a whole)
@@ -1009,6 +1015,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
         atomicAdd(P.segments + 2 + 3 * PS_N, (unsigned long long)(__builtin_amdgcn_s_memtime() - ps_begin));
         for (int k = 0; k < ShadeClock::N; ++k) atomicAdd(P.segments + 3 + 3 * PS_N + k, shade_clock.clk[k]);
         atomicAdd(P.segments + 3 + 3 * PS_N + ShadeClock::N, ps_outer);
+        for (int k = 0; k < 3; ++k) atomicAdd(P.segments + 4 + 3 * PS_N + ShadeClock::N + k, ps_idle[k]);
     }
 #endif
 #undef PS_START

@@ -1039,7 +1039,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     // ---- per-pass state: radiance records, counters and totals in one block (kept by the
     // scene between calls), the queue pipeline's path state in arrays of this call
     const Counters C{max_depth};
-    constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8 + 2;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
+    constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8 + 6;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
     auto round256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     static_assert((256 + 255 * (SHADE_NUM_CLASSES + 1)) * sizeof(uint32_t) + 256 + N_SEGMENT_WORDS * sizeof(unsigned long long) + 256 <= STATIC_TAIL_BYTES,
                   "counters at the largest depth and the totals fit behind the static array's records");
@@ -1194,6 +1194,12 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
                          names[k], 100.0 * clk / total, trips, trips ? clk / trips : 0.0, trips ? lanes / trips : 0.0);
         }
         std::fprintf(stderr, "[k_paths] other  %5.1f %%, %.0f trips of the outer loop\n", 100.0 * (total - sum) / total, (double)segments[2 + 13 + 10]);
+        {
+            const double node_trips = (double)segments[3 + 3 * 2];
+            if (node_trips > 0)
+                std::fprintf(stderr, "[k_paths]   in a node trip: %.1f lanes hold a hit that waits for shading, %.1f are empty, %.1f can only test shapes\n",
+                             (double)segments[2 + 13 + 11] / node_trips, (double)segments[2 + 13 + 12] / node_trips, (double)segments[2 + 13 + 13] / node_trips);
+        }
         const char* parts[10] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "result", "next ray", "store"};
         for (int k = 0; k < 10; ++k)
             std::fprintf(stderr, "[k_paths]   shade: %-20s %5.1f %% of wave clocks\n", parts[k], 100.0 * (double)segments[2 + 13 + k] / total);
