@@ -13,9 +13,14 @@
  *   stream(seed, pixel, sample)         one 64-bit key per camera path
  *   draw(stream, stage, k)              k-th draw of stage `stage` of that path
  *
- * stage 0 is the camera (jitter du, dv; lens disk pairs; shutter time:
- * renderer.rs:79-80, camera.rs:66,73,78-88); stage b+1 is the material hit at
- * bounce b (material.rs:53,79,119).  A rejection loop simply keeps counting k.
+ * stage 0 is the camera: draws 0 and 1 are the jitter du, dv (renderer.rs:79-80),
+ * draw 2 the shutter time (camera.rs:73), draws 3, 4, ... the pairs of the lens
+ * disk's rejection loop (camera.rs:66,78-88).  The reference draws the time after
+ * the pairs; here it has an index of its own so that it does not depend on how
+ * many pairs the loop takes -- and a pinhole camera (lens_radius = 0), which
+ * multiplies the loop's result by zero, need not run it.  Stage b+1 is the
+ * material hit at bounce b (material.rs:53,79,119).  A rejection loop simply keeps
+ * counting k.
  *
  * mirt_seq_* is a plain sequential generator over the same mixer for host-side
  * set-up work (scene generation, BVH axis draws, Perlin tables), standing in

@@ -595,10 +595,13 @@ inline Vec3 random_in_unit_disk(PathRng& rng) {
 // camera.rs:65-76
 inline Ray camera_ray(const mirt_camera& c, PathRng& rng, double s, double t) {
     Vec3 origin(c.origin), llc(c.lower_left_corner), horizontal(c.horizontal), vertical(c.vertical), cu(c.u), cv(c.v);
+    // (the sampler gives the shutter time a draw index of its own, before the lens pairs, so that it does not
+    // depend on how many pairs the rejection loop takes: include/mirt_rng.h.  The operations are camera.rs's.)
+    const double shutter = rng.random_double();
     Vec3 rd = c.lens_radius * random_in_unit_disk(rng);
     Vec3 offset = cu * rd.x() + cv * rd.y();
     Vec3 direction = llc + s * horizontal + t * vertical - origin - offset;
-    double time = c.time_start + rng.random_double() * (c.time_end - c.time_start);
+    double time = c.time_start + shutter * (c.time_end - c.time_start);
     return Ray(origin + offset, direction, time);
 }
 
