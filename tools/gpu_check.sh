@@ -9,5 +9,5 @@ for c in ${@:-C2 C3 C4 C5}; do
     python -c "import sys,json; d=json.load(sys.stdin); print('$c', round(d['value'],1), 'Msamples/s', {k: round(x,1) for k,x in d.get('kernel_ms',{}).items() if x})" || exit 1
 done
 if [ -f ray_tracer_amd/csrc/libmirt_stats.so ]; then
-  MIRT_LIBMIRT=$PWD/ray_tracer_amd/csrc/libmirt_stats.so timeout -k 10 120 python bench.py --config C2 --spp 64 --steps 1 --warmup 1 --cpu-seconds 0 2>&1 | grep "k_paths\]" | tail -15
+  MIRT_LIBMIRT=$PWD/ray_tracer_amd/csrc/libmirt_stats.so timeout -k 10 120 python bench.py --config C2 --spp 64 --steps 1 --warmup 1 --cpu-seconds 0 2>&1 | grep "k_paths\]" | tail -16
 fi
