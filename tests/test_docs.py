@@ -1,5 +1,6 @@
-"""INTEGRATION.md quotes the Rust binding under ffi/ instead of paraphrasing it: every ```rust block of its
-section 2 must be found word for word in ffi/src/ffi.rs or ffi/src/flatten.rs (two documents, one binding)."""
+"""The integration notes quote the Rust binding under ffi/ instead of paraphrasing it: every ```rust block of their
+section on the Rust side must be found word for word in ffi/src/ffi.rs or ffi/src/flatten.rs (two documents, one
+binding)."""
 import os
 import re
 

@@ -1,4 +1,4 @@
-"""Development tool: the tables of DESIGN.md section 3 from the records under profiles/.
+"""Development tool: the counter and throughput tables of the design notes from the records under profiles/.
 usage: python tools/design_tables.py [tag]      (default r03)"""
 import json
 import os
