@@ -150,10 +150,19 @@ struct CullRay {
     __device__ __forceinline__ float c_far(int a) const { return a == 0 ? far_xy.x : a == 1 ? far_xy.y : far_z.x; }
     __device__ __forceinline__ void set(const RayD& r, bool cull) {
         const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
-        float size = 0.0f, far[3];
+        float size = 0.0f, far[3], inv32[3];
+        // A direction component beyond ~1e30 has a reciprocal that f32 holds as a denormal or as zero, and the
+        // bounds above speak of normal numbers: such a ray is not culled at all.  (A component of zero, or too
+        // small for f32, gives an infinite reciprocal, which only ever drops a constraint; a NaN fails the
+        // comparison.)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float i32 = __builtin_amdgcn_rcpf((float)d[a]);
+            inv32[a] = __builtin_amdgcn_rcpf((float)d[a]);
+            cull = cull && __builtin_fabsf(inv32[a]) >= 1.0e-30f;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float i32 = inv32[a];
             const float p = (float)o[a] * i32;
             const float e = __builtin_fabsf(p) * 0x1.0p-19f;
             size += __builtin_fabsf(i32) + __builtin_fabsf(p);
@@ -185,7 +194,7 @@ struct CullRay {
             inv_q[a] = i32 * grid.step[a];
             e[a] = (__builtin_fabsf(p) + __builtin_fabsf(inv_q[a]) * grid.half[a]) * 0x1.0p-18f;
             size += __builtin_fabsf(i32) + __builtin_fabsf(p) + __builtin_fabsf(inv_q[a]) * grid.half[a];
-            least = fminf(least, __builtin_fabsf(inv_q[a]));
+            least = fminf(least, fminf(__builtin_fabsf(inv_q[a]), __builtin_fabsf(i32)));  // (the reciprocal itself must be a normal number too)
             c[a] = p;
             off[a] = i32 < 0.0f ? 16u : 0u;  // the rotation that brings the near bound of a QBox dword into its low half
         }
@@ -293,8 +302,10 @@ __device__ __forceinline__ void slab_pair_q(uint32_t x0, uint32_t x1, uint32_t y
 // image: the culling range (t_lo, t_hi] must contain every t the f64 tests can accept.
 // An infinite x is returned as it is (inf - inf * 2e-6 would be a NaN: a range end that the min / max
 // of the culling tests would silently drop).
-__device__ __forceinline__ float f32_not_below(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x + fabs(x) * 2.0e-6); }
-__device__ __forceinline__ float f32_not_above(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x - fabs(x) * 2.0e-6); }
+// The 1e-30 covers what is absolute in the f32 evaluation of a bound's t: products and sums that fall below f32's
+// normal range are rounded to multiples of 1.4e-45, whatever their size.
+__device__ __forceinline__ float f32_not_below(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x + (fabs(x) * 2.0e-6 + 1.0e-30)); }
+__device__ __forceinline__ float f32_not_above(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x - (fabs(x) * 2.0e-6 + 1.0e-30)); }
 
 // The reference's slab test (aabb.rs:24-51) on every gate of shape `prim`.  Rarely needed: a
 // call, so that its registers are not the kernels'.

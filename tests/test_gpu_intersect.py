@@ -315,3 +315,58 @@ def test_cubes_of_every_description(oracle):
             _compare(scene.hit(rays, t_min=t_min, t_max=t_max), ref_r, f"cubes, range ({t_min}, {t_max})")
     finally:
         scene.close()
+
+
+def _rays_nobody_would_send(n, seed, shapes):
+    """Components of any magnitude from 1e-310 to 1e300, zeros of both signs, infinities, NaN, origins on the
+    shapes' own parameters, directions along axes."""
+    rng = np.random.default_rng(seed)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310, 1e-300, 1e300, -1e300, 1.0, -1.0, 0.001])
+    rays = np.zeros(n, dtype=api.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-14.0, 14.0, (n, 3))
+    rays["direction"] = rng.uniform(-1.0, 1.0, (n, 3))
+    rays["time"] = rng.uniform(-0.5, 1.5, n)
+    wild = rng.random(n) < 0.33
+    rays["direction"][wild] *= (10.0 ** rng.uniform(-300, 300, (n, 3)))[wild]
+    wild = rng.random(n) < 0.15
+    rays["origin"][wild] *= (10.0 ** rng.uniform(-30, 30, (n, 3)))[wild]
+    pick = rng.integers(0, len(shapes), n)
+    for i in np.nonzero(rng.random(n) < 0.2)[0][:2000]:
+        f = shapes[pick[i]].f
+        rays["origin"][i] = (f[0], f[1], f[2]) if rng.random() < 0.5 else (f[0], f[2], f[4])
+    for i in np.nonzero(rng.random(n) < 0.1)[0]:
+        d = np.zeros(3)
+        d[rng.integers(0, 3)] = rng.choice([-1.0, 1.0, 1e-200, 1e200])
+        rays["direction"][i] = d
+    for i in np.nonzero(rng.random(n) < 0.25)[0]:
+        rays[("origin", "direction")[rng.integers(0, 2)]][i, rng.integers(0, 3)] = special[rng.integers(0, len(special))]
+    nasty = rng.random(n) < 0.05
+    rays["time"][nasty] = special[rng.integers(0, len(special), np.count_nonzero(nasty))]
+    return rays
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rays_of_any_magnitude_and_ranges_of_either_sign(seed, oracle):
+    """Hittable::hit for rays nobody would send, with the renderer's (0.001, inf), a range that begins below zero and
+    a tiny t_min: all three traversals against the oracle.  (A direction component beyond 1e38 has no f32
+    reciprocal to cull with, and with a negative t_min the hits at t ~ -1e-43 that such a ray makes count: the
+    culling once dropped some of them.  tools/ray_soak.py runs the same over thousands of worlds.)"""
+    import test_gpu_fuzz as fz
+
+    kind = seed % 4
+    built, _, _, _ = fz._random_world(seed, [(24, 90), (1 + seed % 5, 16), (1 + seed % 4, 11), (300, 900)][kind], planar=kind == 2)
+    rays = _rays_nobody_would_send(20000, 77 + seed, built.shapes)
+    # the case found by the soak, as it was found (5 shapes: spheres and a ground sphere)
+    rays["origin"][0] = (0.7430995077367477, -11.200546938540313, 12.48976460943209)
+    rays["direction"][0] = (1.460231731918684e-72, -8.41632469090724e+43, 7.040029465134746e+43)
+    rays["time"][0] = 1e300
+    scene = api.Scene(built.desc)
+    try:
+        for t_min, t_max in ((0.001, float("inf")), (-5.0, 40.0), (1e-9, 1e30)):
+            ref, _ = oracle.intersect(built.desc, rays, t_min=t_min, t_max=t_max)
+            ref_list, _ = oracle.intersect(built.desc, rays, t_min=t_min, t_max=t_max, use_bvh=False)
+            _compare(scene.hit(rays, t_min, t_max), ref, f"wild rays, fast, ({t_min}, {t_max})")
+            _compare(scene.hit(rays, t_min, t_max, traversal=abi.TRAVERSE_REFERENCE), ref, f"wild rays, reference-order, ({t_min}, {t_max})")
+            _compare(scene.hit(rays, t_min, t_max, use_bvh=False), ref_list, f"wild rays, list, ({t_min}, {t_max})")
+    finally:
+        scene.close()
