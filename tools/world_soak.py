@@ -3,7 +3,9 @@ of radius zero, tiny, huge or negative, cubes with unordered or coinciding corne
 ends swapped, shapes on top of each other, moving spheres whose shutter span is empty, negative or not a power of
 two, everything scaled by 10^-30 .. 10^30 -- with ordinary and wild rays; all three traversals against the oracle.
 A world the library refuses to create (mirt_scene_create's own checks) is counted, not an error.
-  usage: python tools/world_soak.py [first seed] [worlds] [rays per world]"""
+  usage: python tools/world_soak.py [first seed] [worlds] [rays per world] [big]
+`big`: worlds of 900 .. 20 000 shapes instead (the path kernel's other placements of the tree: nodes in LDS with the
+records in global memory, 28-byte nodes, everything from global memory, 32-bit stack entries)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
@@ -15,13 +17,14 @@ from ray_tracer_amd import _abi as abi, api
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 worlds = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 8000
+big = len(sys.argv) > 4
 failed = refused = total = 0
 t0 = time.perf_counter()
 for w in range(worlds):
     seed = first + w
     rng = np.random.default_rng(4242 + seed)
     scale = 10.0 ** rng.choice([0, 0, 0, -30, -8, 5, 12, 30])
-    count = int(rng.choice([1, 2, 3, 7, 20, 60, 400]))
+    count = int(rng.choice([900, 1500, 2500, 3600, 3800, 6000, 20000, 70000] if big else [1, 2, 3, 7, 20, 60, 400]))
     shapes = []
     for k in range(count):
         c = rng.uniform(-6.0, 6.0, 3)
