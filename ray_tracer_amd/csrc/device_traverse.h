@@ -156,10 +156,8 @@ struct CullRay {
         // small for f32, gives an infinite reciprocal, which only ever drops a constraint; a NaN fails the
         // comparison.)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            inv32[a] = __builtin_amdgcn_rcpf((float)d[a]);
-            cull = cull && __builtin_fabsf(inv32[a]) >= 1.0e-30f;
-        }
+        for (int a = 0; a < 3; ++a) inv32[a] = __builtin_amdgcn_rcpf((float)d[a]);
+        cull = cull && fminf(fminf(__builtin_fabsf(inv32[0]), __builtin_fabsf(inv32[1])), __builtin_fabsf(inv32[2])) >= 1.0e-30f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float i32 = inv32[a];
@@ -304,8 +302,9 @@ __device__ __forceinline__ void slab_pair_q(uint32_t x0, uint32_t x1, uint32_t y
 // of the culling tests would silently drop).
 // The 1e-30 covers what is absolute in the f32 evaluation of a bound's t: products and sums that fall below f32's
 // normal range are rounded to multiples of 1.4e-45, whatever their size.
-__device__ __forceinline__ float f32_not_below(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x + (fabs(x) * 2.0e-6 + 1.0e-30)); }
-__device__ __forceinline__ float f32_not_above(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x - (fabs(x) * 2.0e-6 + 1.0e-30)); }
+// (added in f32: 1e-30 is a normal number there, and a sum of two f32 values is off by 6e-8 of itself at most)
+__device__ __forceinline__ float f32_not_below(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x + fabs(x) * 2.0e-6) + 1.0e-30f; }
+__device__ __forceinline__ float f32_not_above(double x) { return fabs(x) == __builtin_inf() ? (float)x : (float)(x - fabs(x) * 2.0e-6) - 1.0e-30f; }
 
 // The reference's slab test (aabb.rs:24-51) on every gate of shape `prim`.  Rarely needed: a
 // call, so that its registers are not the kernels'.
