@@ -467,6 +467,32 @@ def turbulence(pl, p, depth):  # perlin.rs:38-50
     return abs(accumulator)
 
 
+def perlin_new(seed):
+    """Perlin::new, perlin.rs:20-36, 88-98, with draws from mirt_seq(seed): 256 x Vec3::random(rng, -1.0, 1.0).unit()
+    (vec3.rs:27-33: gen_range per component, x first), then three permutations, each (0..256).rev() shuffled as
+    rand 0.7.3's SliceRandom::shuffle does it: for i in (1..len).rev() { swap(i, gen_range(0, i + 1)) }."""
+    rng = SeqRng(seed)
+
+    def gen_range(lower, upper):  # mirt_seq_range
+        return lower + (upper - lower) * (float(rng.u64() >> 11) * 2.0 ** -53)
+
+    vecs = []
+    for _ in range(256):
+        x = gen_range(-1.0, 1.0)
+        y = gen_range(-1.0, 1.0)
+        z = gen_range(-1.0, 1.0)
+        vecs.append(unit((x, y, z)))
+
+    def generate_perm():
+        vec = list(range(255, -1, -1))
+        for i in range(255, 0, -1):
+            j = rng.gen_range_int(i + 1)
+            vec[i], vec[j] = vec[j], vec[i]
+        return vec
+
+    return {"vecs": vecs, "perm_x": generate_perm(), "perm_y": generate_perm(), "perm_z": generate_perm()}
+
+
 def fclamp(x, lo, hi):  # texture.rs:195-205
     if x < lo:
         x = lo
@@ -561,6 +587,26 @@ def material_scatter(world, m, rng, ray, hit):  # material.rs:191-199 -> (scatte
 
 
 # ---------------------------------------------------------------- camera.rs
+
+
+def cross(a, b):  # vec3.rs:92-98
+    return (a[1] * b[2] - a[2] * b[1], -(a[0] * b[2] - a[2] * b[0]), a[0] * b[1] - a[1] * b[0])
+
+
+def camera_new(look_from, look_at, v_up, vertical_fov, aspect, aperture, focus_distance, time_start, time_end):  # camera.rs:21-63
+    lens_radius = aperture / 2.0
+    theta = vertical_fov * math.pi / 180.0
+    half_height = math.tan(theta / 2.0)
+    half_width = aspect * half_height
+    w = unit(v_sub(look_from, look_at))
+    u = unit(cross(v_up, w))
+    v = cross(w, u)
+    origin = look_from
+    lower_left_corner = v_sub(v_sub(v_sub(origin, v_scale(u, half_width * focus_distance)), v_scale(v, half_height * focus_distance)), v_scale(w, focus_distance))
+    horizontal = v_scale(u, 2.0 * half_width * focus_distance)
+    vertical = v_scale(v, 2.0 * half_height * focus_distance)
+    return {"origin": origin, "lower_left_corner": lower_left_corner, "horizontal": horizontal, "vertical": vertical, "u": u, "v": v, "w": w,
+            "lens_radius": lens_radius, "time_start": time_start, "time_end": time_end}
 
 
 def random_in_unit_disk(rng):  # camera.rs:78-88

@@ -192,3 +192,28 @@ def test_ties_and_range_ends_agree():
                         assert hit.side == ref["side"][i] and _same(hit.t, float(ref["t"][i]))
                         ties += 1
                 assert ties > 20 or t_min == t_max
+
+
+def test_camera_new_agrees():
+    """Camera::new (camera.rs:21-63) as the host mirror computes it (mirt_host_camera_new), field by field."""
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        look_from, look_at = tuple(rng.uniform(-20.0, 20.0, 3)), tuple(rng.uniform(-5.0, 5.0, 3))
+        fov, aspect, aperture, focus = rng.uniform(1.0, 170.0), rng.uniform(0.3, 3.0), rng.choice([0.0, 0.1, 2.0]), rng.choice([1.0, 10.0, 37.5])
+        cam = api.Camera.new(look_from, look_at, (0.0, 1.0, 0.0), fov, aspect, aperture, focus, 0.0, 1.0)
+        mine = pyref.camera_new(tuple(float(x) for x in look_from), tuple(float(x) for x in look_at), (0.0, 1.0, 0.0), float(fov), float(aspect),
+                                float(aperture), float(focus), 0.0, 1.0)
+        theirs = pyref.camera_of(cam.c)
+        for key, value in mine.items():
+            assert theirs[key] == value, (key, theirs[key], value)
+
+
+def test_perlin_new_agrees():
+    """Perlin::new (perlin.rs:20-36, 88-98) as the host mirror fills its tables (mirt_host_perlin_new)."""
+    for seed in (1, 77, 123456789):
+        p = abi.Perlin()
+        assert abi.libhost().mirt_host_perlin_new(seed, C.byref(p)) == 0
+        mine = pyref.perlin_new(seed)
+        assert [tuple(float(x) for x in p.vecs[k]) for k in range(256)] == mine["vecs"]
+        assert list(p.perm_x) == mine["perm_x"] and list(p.perm_y) == mine["perm_y"] and list(p.perm_z) == mine["perm_z"]
+        assert sorted(mine["perm_x"]) == list(range(256))
