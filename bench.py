@@ -343,6 +343,8 @@ def main():
             "handover": {"bounce": int(step_stats[-1]["handover_bounce"]),
                          "path_kernel_segments_frac": tot["segments_paths"] / max(1.0, tot["segments"])},
             "library_build_id": abi.libmirt().mirt_build_id().decode(),
+            "parity": "unpinned by the reference (it holds no fixtures and cannot be built here); bit-exact hits and images within "
+                      "one level against the repository's own CPU restatement, tests/ -m gpu",
             "scene_upload_ms": scene_upload_ms,
             "library_first_call_ms": first_call_ms,
             "mrays_per_s": tot["segments"] / elapsed / 1e6,
