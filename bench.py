@@ -399,7 +399,9 @@ def main():
                 roof["valu_issue_busy"] = busy
                 roof["lanes_active_per_valu_instruction"] = lanes
                 if busy is not None and lanes is not None:
-                    roof["achieved"] = roof["frac"] = busy * lanes / 64.0
+                    # (the busy share's denominator is the mean lifetime of a wave, which is shorter than its SIMD's by
+                    # the launch's tail: on a kernel that saturates the vector ALU the share can read 1.01)
+                    roof["achieved"] = roof["frac"] = min(1.0, busy) * lanes / 64.0
                 roof["counters_source"] = os.path.relpath(pmc_path, ROOT) + " (counters of one launch, per path x this run's paths per launch)"
                 roof["counters_build_id"] = pmc.get("library_build_id")
                 roof["counters_stale"] = pmc.get("library_build_id") != result["library_build_id"]
