@@ -890,10 +890,15 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 RayD r;
                 if (bounce0 == 0) {
                     const RenderParams q = load_kernarg<RenderParams>(args, sizeof(DScene) + sizeof(Paths));
-                    // slot i = sample (sample_base + i / n_pixels) of the (i % n_pixels)-th pixel, as in k_raygen
+                    // Path i of the pass = sample (i % n_samples) of the (i / n_samples)-th pixel: the 64 paths a wave
+                    // takes together are samples of one pixel (or of a few neighbours), so its lanes walk the tree in
+                    // step down to the first hit and mostly meet the same material there: -1 to -6 % of the kernel's
+                    // time against taking the pass sample by sample, as k_raygen numbers it.  The radiance record
+                    // is the path's index either way; k_accumulate_by_pixel reads this numbering.
                     slot = i;
-                    const uint32_t idx = q.px.idx(slot % q.n_pixels);
-                    PathRng rng{mirt_rng_stream(q.seed, idx, q.sample_base + slot / q.n_pixels), 0u, 0u};
+                    const uint32_t k = slot / q.n_samples;
+                    const uint32_t idx = q.px.idx(k);
+                    PathRng rng{mirt_rng_stream(q.seed, idx, q.sample_base + (slot - k * q.n_samples)), 0u, 0u};
                     r = camera_ray(q.cam, q.width, q.height, idx, rng);
                     beta = v3(1.0, 1.0, 1.0);
                     stream = rng.stream;
@@ -1083,6 +1088,74 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, 
         atomicAdd(P.segments + 0, seg);
         if (rp.handover < rp.max_depth)
             atomicAdd(P.segments + 1, (unsigned long long)(rp.handover == 0 ? rp.n_paths : P.counters[C.live(rp.handover)]));
+    }
+}
+
+// The same for a pass whose records are numbered pixel by pixel (k_paths from the camera ray: sample s of the k-th
+// pixel in record k * n_samples + s).  A wave takes 64 pixels; their records for eight samples at a time -- 256
+// contiguous bytes per pixel -- are read with every lane on its own 16 bytes of four such runs (whole cache lines)
+// and handed through LDS to the lane that owns the pixel, which adds them in sample order.
+constexpr uint32_t ACC_TILE = 8;                               // samples per tile
+constexpr uint32_t ACC_PIXEL_BYTES = ACC_TILE * 32 + 16;       // LDS bytes per pixel of a tile (rows four banks apart)
+constexpr uint32_t ACC_WAVES = 4;
+__global__ __launch_bounds__(ACC_WAVES * 64) void k_accumulate_by_pixel(Paths P, RenderParams rp, double* __restrict__ accum) {
+    __shared__ __align__(16) char s_tile[ACC_WAVES][64 * ACC_PIXEL_BYTES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    char* tile = s_tile[wave];
+    const uint32_t n_groups = (rp.n_pixels + 63u) >> 6, S = rp.n_samples;
+    const char* __restrict__ records = reinterpret_cast<const char*>(P.radiance);
+    for (uint32_t group = blockIdx.x * ACC_WAVES + wave; group < n_groups; group += gridDim.x * ACC_WAVES) {
+        const uint32_t k0 = group << 6, k = k0 + lane;
+        const uint32_t pixels = min(64u, rp.n_pixels - k0);
+        const bool mine = k < rp.n_pixels;
+        const size_t idx = mine ? rp.px.idx(k) : 0;
+        double r = 0.0, g = 0.0, b = 0.0;
+        if (mine) r = accum[3 * idx + 0], g = accum[3 * idx + 1], b = accum[3 * idx + 2];
+        for (uint32_t s0 = 0; s0 < S; s0 += ACC_TILE) {
+            const uint32_t T = min(ACC_TILE, S - s0);
+            if (pixels == 64u && T == ACC_TILE) {
+                // sixteen loads in flight per lane, then sixteen LDS writes
+                double2 v[16];
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    const uint32_t piece = j * 64u + lane, pl = piece >> 4, w = piece & 15u;
+                    v[j] = *reinterpret_cast<const double2*>(records + ((size_t)(k0 + pl) * S + s0) * 32u + w * 16u);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    const uint32_t piece = j * 64u + lane, pl = piece >> 4, w = piece & 15u;
+                    *reinterpret_cast<double2*>(tile + pl * ACC_PIXEL_BYTES + w * 16u) = v[j];
+                }
+            } else {
+                const uint32_t per_pixel = 2u * T;  // 16-byte pieces of one pixel's run
+                for (uint32_t piece = lane; piece < pixels * per_pixel; piece += 64u) {
+                    const uint32_t pl = piece / per_pixel, w = piece - pl * per_pixel;
+                    *reinterpret_cast<double2*>(tile + pl * ACC_PIXEL_BYTES + w * 16u) =
+                        *reinterpret_cast<const double2*>(records + ((size_t)(k0 + pl) * S + s0) * 32u + w * 16u);
+                }
+            }
+            // (one wave writes and reads its own tile: its LDS operations complete in program order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (mine) {
+                const double* __restrict__ mine_rows = reinterpret_cast<const double*>(tile + lane * ACC_PIXEL_BYTES);
+                for (uint32_t t = 0; t < T; ++t) {
+                    r += mine_rows[4 * t + 0];
+                    g += mine_rows[4 * t + 1];
+                    b += mine_rows[4 * t + 2];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (mine) accum[3 * idx + 0] = r, accum[3 * idx + 1] = g, accum[3 * idx + 2] = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // (this numbering belongs to passes that k_paths runs from the camera ray: see k_accumulate)
+        atomicAdd(P.segments + 0, (unsigned long long)rp.n_paths);
+        atomicAdd(P.segments + 1, (unsigned long long)rp.n_paths);
     }
 }
 

@@ -1168,7 +1168,11 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
             ++launches_shade;
         }
         HIP_TRY(timer.begin(stream, EventTimer::ACCUMULATE));
-        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(scene, n_pixels, 8)), dim3(BLOCK), 0, stream, P, rp, d_accum);
+        if (rp.handover == 0)  // k_paths from the camera ray numbers its records pixel by pixel
+            hipLaunchKernelGGL(k_accumulate_by_pixel, dim3(std::min<uint32_t>((n_pixels + 64 * ACC_WAVES - 1) / (64 * ACC_WAVES), (uint32_t)scene->cu_count * 2u)),
+                               dim3(ACC_WAVES * 64), 0, stream, P, rp, d_accum);
+        else
+            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(scene, n_pixels, 8)), dim3(BLOCK), 0, stream, P, rp, d_accum);
         HIP_TRY(timer.end(stream));
         HIP_TRY(hipGetLastError());
         if (timer.enabled) {

@@ -350,8 +350,8 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 uint64_t stream = 0;
                 const uint32_t slot = base + lane;
                 if (mine) {
-                    const uint32_t idx = rp.px.idx(slot % rp.n_pixels);
-                    PathRng rng{mirt_rng_stream(rp.seed, idx, rp.sample_base + slot / rp.n_pixels), 0u, 0u};
+                    const uint32_t idx = rp.px.idx(slot / rp.n_samples);  // (numbered pixel by pixel, as k_paths does)
+                    PathRng rng{mirt_rng_stream(rp.seed, idx, rp.sample_base + slot % rp.n_samples), 0u, 0u};
                     r = camera_ray(rp.cam, rp.width, rp.height, idx, rng);
                     stream = rng.stream;
                 }
