@@ -210,7 +210,7 @@ typedef struct mirt_render_opts {
     uint32_t sample_begin;   /* render samples s in [sample_begin, sample_end) of 0..spp */
     uint32_t sample_end;     /* 0 = spp */
     uint32_t paths_per_pass; /* target number of paths per pass; 0 = default (2^29 when the path kernel
-                              * runs from the camera ray, 32 B of device memory per path; 2^26 otherwise,
+                              * runs from the camera ray, 24 B of device memory per path; 2^26 otherwise,
                               * 173 B per path; either way at most a quarter of the free device memory) */
     int32_t profile;         /* 1 = time each kernel class with HIP events (fills mirt_stats.ms_*) */
     /* Tile split across devices: of the pixel range, cut into tiles of tile_size
@@ -277,7 +277,7 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
 void mirt_scene_destroy(mirt_scene* scene);
 
 /* Frees the per-pass buffers a render call left with the scene for the next one (by default up to
- * 17 GB, see mirt_render_opts.paths_per_pass); the next render call allocates them again.  For
+ * 13 GB, see mirt_render_opts.paths_per_pass); the next render call allocates them again.  For
  * processes that hold several scenes or need the device memory for something else between frames. */
 int mirt_scene_trim(mirt_scene* scene);
 

@@ -49,8 +49,8 @@ struct Paths {
     double *bx, *by, *bz;                        // product of attenuations so far
     double *hit_t;                               // closest hit of the current ray
     uint32_t* hit_ref;                           // shape index | side << 28, or HIT_MISS
-    double4* radiance;                           // radiance of the finished path (x, y, z; w unused): one
-                                                 // 32-byte record per path, written once, by one lane
+    double* radiance;                            // radiance of the finished path: one record of three doubles
+                                                 // per path, written once, by one lane
     uint64_t* stream;                            // sampler key of the path
     uint32_t* live[2];                           // live queues (slot indices), ping-pong by bounce parity
     uint8_t* cls_q;                              // shade class of live entry i (queue order)
@@ -116,12 +116,13 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 // compare of the flag turned into 0 / 1: two vector instructions per vote).
 __device__ __forceinline__ unsigned long long vote(bool flag) { return __builtin_amdgcn_ballot_w64(flag); }
 
-// Three doubles into the path's 32-byte record: finished paths are scattered over the slots,
-// and a record keeps each path's result inside one 32-byte sector (three separate arrays
-// measured 13x the algorithmic bytes at the memory side).
+// Three doubles into the path's record: finished paths are scattered over the slots, and a record keeps each
+// path's result together (three separate arrays measured 13x the algorithmic bytes at the memory side).
+constexpr uint32_t RECORD_DOUBLES = 3, RECORD_BYTES = RECORD_DOUBLES * 8;
 __device__ __forceinline__ void store_radiance(const Paths& P, uint32_t slot, const V3& c) {
-    double* __restrict__ v = reinterpret_cast<double*>(P.radiance + slot);
-    *reinterpret_cast<double2*>(v) = make_double2(c.x, c.y);
+    double* __restrict__ v = P.radiance + (size_t)slot * RECORD_DOUBLES;
+    v[0] = c.x;
+    v[1] = c.y;
     v[2] = c.z;
 }
 
@@ -1071,7 +1072,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, 
         double r = accum[3 * idx + 0], g = accum[3 * idx + 1], b = accum[3 * idx + 2];
         for (uint32_t s = 0; s < rp.n_samples; ++s) {
             const size_t slot = (size_t)s * rp.n_pixels + k;
-            const double* __restrict__ v = reinterpret_cast<const double*>(P.radiance + slot);
+            const double* __restrict__ v = P.radiance + slot * RECORD_DOUBLES;
             r += v[0];
             g += v[1];
             b += v[2];
@@ -1092,18 +1093,19 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(Paths P, RenderParams rp, 
 }
 
 // The same for a pass whose records are numbered pixel by pixel (k_paths from the camera ray: sample s of the k-th
-// pixel in record k * n_samples + s).  A wave takes 64 pixels; their records for eight samples at a time -- 256
-// contiguous bytes per pixel -- are read with every lane on its own 16 bytes of four such runs (whole cache lines)
-// and handed through LDS to the lane that owns the pixel, which adds them in sample order.
-constexpr uint32_t ACC_TILE = 8;                               // samples per tile
-constexpr uint32_t ACC_PIXEL_BYTES = ACC_TILE * 32 + 16;       // LDS bytes per pixel of a tile (rows four banks apart)
+// pixel in record k * n_samples + s).  A wave takes 64 pixels; their records for eight samples at a time -- 192
+// contiguous bytes per pixel -- are read with every lane on its own 8 bytes of consecutive runs (whole cache lines but
+// for the ends) and handed through LDS to the lane that owns the pixel, which adds them in sample order.
+constexpr uint32_t ACC_TILE = 8;                                        // samples per tile
+constexpr uint32_t ACC_RUN_WORDS = ACC_TILE * RECORD_DOUBLES;           // doubles of one pixel's run in a tile
+constexpr uint32_t ACC_PIXEL_BYTES = ACC_RUN_WORDS * 8 + 8;             // LDS bytes per pixel of a tile (rows 50 banks apart)
 constexpr uint32_t ACC_WAVES = 4;
 __global__ __launch_bounds__(ACC_WAVES * 64) void k_accumulate_by_pixel(Paths P, RenderParams rp, double* __restrict__ accum) {
     __shared__ __align__(16) char s_tile[ACC_WAVES][64 * ACC_PIXEL_BYTES];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     char* tile = s_tile[wave];
     const uint32_t n_groups = (rp.n_pixels + 63u) >> 6, S = rp.n_samples;
-    const char* __restrict__ records = reinterpret_cast<const char*>(P.radiance);
+    const double* __restrict__ records = P.radiance;
     for (uint32_t group = blockIdx.x * ACC_WAVES + wave; group < n_groups; group += gridDim.x * ACC_WAVES) {
         const uint32_t k0 = group << 6, k = k0 + lane;
         const uint32_t pixels = min(64u, rp.n_pixels - k0);
@@ -1114,24 +1116,23 @@ __global__ __launch_bounds__(ACC_WAVES * 64) void k_accumulate_by_pixel(Paths P,
         for (uint32_t s0 = 0; s0 < S; s0 += ACC_TILE) {
             const uint32_t T = min(ACC_TILE, S - s0);
             if (pixels == 64u && T == ACC_TILE) {
-                // sixteen loads in flight per lane, then sixteen LDS writes
-                double2 v[16];
+                // twenty-four loads in flight per lane, then as many LDS writes
+                double v[ACC_RUN_WORDS];
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) {
-                    const uint32_t piece = j * 64u + lane, pl = piece >> 4, w = piece & 15u;
-                    v[j] = *reinterpret_cast<const double2*>(records + ((size_t)(k0 + pl) * S + s0) * 32u + w * 16u);
+                for (uint32_t j = 0; j < ACC_RUN_WORDS; ++j) {
+                    const uint32_t word = j * 64u + lane, pl = word / ACC_RUN_WORDS, w = word - pl * ACC_RUN_WORDS;
+                    v[j] = records[((size_t)(k0 + pl) * S + s0) * RECORD_DOUBLES + w];
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) {
-                    const uint32_t piece = j * 64u + lane, pl = piece >> 4, w = piece & 15u;
-                    *reinterpret_cast<double2*>(tile + pl * ACC_PIXEL_BYTES + w * 16u) = v[j];
+                for (uint32_t j = 0; j < ACC_RUN_WORDS; ++j) {
+                    const uint32_t word = j * 64u + lane, pl = word / ACC_RUN_WORDS, w = word - pl * ACC_RUN_WORDS;
+                    *reinterpret_cast<double*>(tile + pl * ACC_PIXEL_BYTES + w * 8u) = v[j];
                 }
             } else {
-                const uint32_t per_pixel = 2u * T;  // 16-byte pieces of one pixel's run
-                for (uint32_t piece = lane; piece < pixels * per_pixel; piece += 64u) {
-                    const uint32_t pl = piece / per_pixel, w = piece - pl * per_pixel;
-                    *reinterpret_cast<double2*>(tile + pl * ACC_PIXEL_BYTES + w * 16u) =
-                        *reinterpret_cast<const double2*>(records + ((size_t)(k0 + pl) * S + s0) * 32u + w * 16u);
+                const uint32_t per_pixel = RECORD_DOUBLES * T;  // doubles of one pixel's run
+                for (uint32_t word = lane; word < pixels * per_pixel; word += 64u) {
+                    const uint32_t pl = word / per_pixel, w = word - pl * per_pixel;
+                    *reinterpret_cast<double*>(tile + pl * ACC_PIXEL_BYTES + w * 8u) = records[((size_t)(k0 + pl) * S + s0) * RECORD_DOUBLES + w];
                 }
             }
             // (one wave writes and reads its own tile: its LDS operations complete in program order)
@@ -1141,9 +1142,9 @@ __global__ __launch_bounds__(ACC_WAVES * 64) void k_accumulate_by_pixel(Paths P,
             if (mine) {
                 const double* __restrict__ mine_rows = reinterpret_cast<const double*>(tile + lane * ACC_PIXEL_BYTES);
                 for (uint32_t t = 0; t < T; ++t) {
-                    r += mine_rows[4 * t + 0];
-                    g += mine_rows[4 * t + 1];
-                    b += mine_rows[4 * t + 2];
+                    r += mine_rows[RECORD_DOUBLES * t + 0];
+                    g += mine_rows[RECORD_DOUBLES * t + 1];
+                    b += mine_rows[RECORD_DOUBLES * t + 2];
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -156,7 +156,7 @@ struct Workspace {
 // copy at its own address until the process ends.
 constexpr uint32_t STATIC_PASS_PATHS = MIRT_STATIC_PASS_PATHS;
 constexpr size_t STATIC_TAIL_BYTES = 16 * 1024;  // counters (at most 2551 words at depth 255) + totals
-constexpr size_t STATIC_SCRATCH_BYTES = (size_t)STATIC_PASS_PATHS * sizeof(double4) + STATIC_TAIL_BYTES;
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)STATIC_PASS_PATHS * 32 + STATIC_TAIL_BYTES;  // (room for 32-byte records; they are 24)
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 namespace {
@@ -1013,13 +1013,13 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
         return fail(MIRT_ERR_UNSUPPORTED, "%u pixels selected, at most %u fit a pass of mirt_render_accumulate_static: split the frame into pixel ranges",
                     n_pixels, STATIC_PASS_PATHS);
 
-    // Default pass: 2^29 paths when the path kernel runs from the camera ray (17 GB of radiance
+    // Default pass: 2^29 paths when the path kernel runs from the camera ray (13 GB of radiance
     // records: each launch ends with a tail of a few deep paths, ~0.8 ms on RTIOW, so few large
     // launches beat many small ones: +7.5 % over 2^26); 2^26 for the per-bounce pipeline (173 B of path state
     // per path + the record: against 2^23 an eighth of the launches, most of which find almost empty queues:
     // 1 369 instead of 787 Msamples/s on RTIOW); either way at most a quarter of the device memory that is free.
     uint64_t target = o.paths_per_pass ? o.paths_per_pass : (from_start ? (1ull << 29) : (1ull << 26));
-    const size_t bytes_per_path = from_start ? sizeof(double4) : 208;
+    const size_t bytes_per_path = from_start ? RECORD_BYTES : 176 + RECORD_BYTES;
     if (static_scratch) target = std::min<uint64_t>(target, STATIC_PASS_PATHS);
     if (!o.paths_per_pass && !static_scratch) {
         size_t free_bytes = 0, total_bytes = 0;
@@ -1043,7 +1043,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     auto round256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     static_assert((256 + 255 * (SHADE_NUM_CLASSES + 1)) * sizeof(uint32_t) + 256 + N_SEGMENT_WORDS * sizeof(unsigned long long) + 256 <= STATIC_TAIL_BYTES,
                   "counters at the largest depth and the totals fit behind the static array's records");
-    const size_t radiance_bytes = round256((size_t)capacity * sizeof(double4));
+    const size_t radiance_bytes = round256((size_t)capacity * RECORD_BYTES);
     const size_t counters_bytes = round256((size_t)C.total() * sizeof(uint32_t));
     const size_t segments_bytes = round256(N_SEGMENT_WORDS * sizeof(unsigned long long));
     Workspace ws;  // declared before the stream work below ends: released after the final synchronise
@@ -1062,7 +1062,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     Paths P;
     std::memset(&P, 0, sizeof P);
     P.capacity = capacity;
-    P.radiance = reinterpret_cast<double4*>(block);
+    P.radiance = reinterpret_cast<double*>(block);
     P.counters = reinterpret_cast<uint32_t*>(static_cast<char*>(block) + radiance_bytes);
     P.segments = reinterpret_cast<unsigned long long*>(static_cast<char*>(block) + radiance_bytes + counters_bytes);
     if (!from_start) {
