@@ -833,6 +833,9 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
     unsigned long long ps_outer = 0;
     unsigned long long ps_idle[3] = {};  // in node trips: lanes holding a hit that waits for shading, empty lanes, lanes that can only test shapes
     const unsigned long long ps_begin = __builtin_amdgcn_s_memtime();
+    // (the 100 MHz counter that all waves share: when the launch began, when the queue ran dry, when each wave ended)
+    const unsigned long long ps_real_begin = __builtin_amdgcn_s_memrealtime();
+    bool ps_saw_dry = false;
 #define PS_START() const unsigned long long ps_t0 = __builtin_amdgcn_s_memtime()
 #define PS_STOP(k, lanes)                                                   \
     do {                                                                    \
@@ -877,6 +880,12 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 next = base;
                 chunk_end = min(base + chunk, n);
                 exhausted = base >= n;
+#ifdef MIRT_PATHS_STATS
+                if (exhausted && !ps_saw_dry) {
+                    ps_saw_dry = true;
+                    if (lane == 0) atomicMax(P.segments + 2 + 16 + 8 + 6 + 0, (1ull << 62) - (unsigned long long)__builtin_amdgcn_s_memrealtime());
+                }
+#endif
             }
             const uint32_t avail = exhausted ? 0u : chunk_end - next;
             const uint32_t rank = mbcnt_lt(need);
@@ -1052,6 +1061,11 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
         for (int k = 0; k < ShadeClock::N; ++k) atomicAdd(P.segments + 3 + 3 * PS_N + k, shade_clock.clk[k]);
         atomicAdd(P.segments + 3 + 3 * PS_N + ShadeClock::N, ps_outer);
         for (int k = 0; k < 3; ++k) atomicAdd(P.segments + 4 + 3 * PS_N + ShadeClock::N + k, ps_idle[k]);
+        const unsigned long long ps_real_end = __builtin_amdgcn_s_memrealtime();
+        atomicMax(P.segments + 2 + 16 + 8 + 6 + 1, (1ull << 62) - ps_real_begin);  // the earliest begin
+        atomicMax(P.segments + 2 + 16 + 8 + 6 + 2, ps_real_end);                    // the latest end
+        atomicAdd(P.segments + 2 + 16 + 8 + 6 + 3, ps_real_end - ps_real_begin);    // sum of the waves' lifetimes
+        atomicAdd(P.segments + 2 + 16 + 8 + 6 + 4, 1ull);                           // waves
     }
 #endif
 #undef PS_START

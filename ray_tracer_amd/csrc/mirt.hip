@@ -1039,7 +1039,7 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
     // ---- per-pass state: radiance records, counters and totals in one block (kept by the
     // scene between calls), the queue pipeline's path state in arrays of this call
     const Counters C{max_depth};
-    constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8 + 6;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
+    constexpr size_t N_SEGMENT_WORDS = 2 + 16 + 8 + 6 + 6;  // [2..] development statistics of k_paths (MIRT_PATHS_STATS builds)
     auto round256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     static_assert((256 + 255 * (SHADE_NUM_CLASSES + 1)) * sizeof(uint32_t) + 256 + N_SEGMENT_WORDS * sizeof(unsigned long long) + 256 <= STATIC_TAIL_BYTES,
                   "counters at the largest depth and the totals fit behind the static array's records");
@@ -1203,6 +1203,15 @@ int render_accumulate_impl(const mirt_scene* scene, const mirt_camera* camera, c
             if (node_trips > 0)
                 std::fprintf(stderr, "[k_paths]   in a node trip: %.1f lanes hold a hit that waits for shading, %.1f are empty, %.1f can only test shapes\n",
                              (double)segments[2 + 13 + 11] / node_trips, (double)segments[2 + 13 + 12] / node_trips, (double)segments[2 + 13 + 13] / node_trips);
+        }
+        {
+            const unsigned long long* w = segments + 2 + 16 + 8 + 6;
+            if (w[4]) {
+                const double begin = (double)((1ull << 62) - w[1]), dry = (double)((1ull << 62) - w[0]), end = (double)w[2];
+                std::fprintf(stderr, "[k_paths]   launch: %.3f ms from the first wave's start to the last wave's end; the queue ran dry %.3f ms before the end; "
+                                     "a wave lived %.3f ms on average (100 MHz clock, last launch of the call)\n",
+                             (end - begin) * 1e-5, (end - dry) * 1e-5, (double)w[3] / (double)w[4] * 1e-5);
+            }
         }
         const char* parts[10] = {"confirm", "surface", "in_sphere", "unit dir", "metal", "dielectric", "lambertian+texture", "result", "next ray", "store"};
         for (int k = 0; k < 10; ++k)

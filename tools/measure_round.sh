@@ -35,6 +35,6 @@ if [ -f ray_tracer_amd/csrc/libmirt_stats.so ]; then
   for c in C2 C3 C4 C5; do
     echo "== $c (python bench.py --config $c --spp ${SPP[$c]} --steps 1 --warmup 1, libmirt_stats.so = -DMIRT_PATHS_STATS, last launch)" >> $OUT/${TAG}_phase_stats.txt
     MIRT_LIBMIRT=$PWD/ray_tracer_amd/csrc/libmirt_stats.so timeout -k 10 120 python bench.py --config $c --spp ${SPP[$c]} --steps 1 --warmup 1 --cpu-seconds 0 --no-profile 2>&1 |
-      grep "k_paths\]" | tail -16 >> $OUT/${TAG}_phase_stats.txt || exit 1
+      grep "k_paths\]" | tail -17 >> $OUT/${TAG}_phase_stats.txt || exit 1
   done
 fi

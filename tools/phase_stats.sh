@@ -4,5 +4,5 @@
 declare -A SPP=([C2]=69 [C3]=32 [C4]=64 [C5]=8)
 for c in ${@:-C2 C3 C4 C5}; do
   echo "== $c (bench.py --config $c --spp ${SPP[$c]} --steps 1 --warmup 1, libmirt_stats.so = -DMIRT_PATHS_STATS, last launch)"
-  MIRT_LIBMIRT=$PWD/ray_tracer_amd/csrc/libmirt_stats.so timeout -k 10 120 python bench.py --config $c --spp ${SPP[$c]} --steps 1 --warmup 1 --cpu-seconds 0 --no-profile 2>&1 | grep "k_paths\]" | tail -16
+  MIRT_LIBMIRT=$PWD/ray_tracer_amd/csrc/libmirt_stats.so timeout -k 10 120 python bench.py --config $c --spp ${SPP[$c]} --steps 1 --warmup 1 --cpu-seconds 0 --no-profile 2>&1 | grep "k_paths\]" | tail -17
 done
