@@ -499,7 +499,7 @@ struct RayWalk {
             CullRay plain;
             plain.set(r, cull.tame);
             if (plain.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) return true;
-        } else if (cull.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max))) {
+        } else if (__builtin_expect(cull.sure_to_cross(&rec->sure[0][0], f32_not_below(t_min), f32_not_above(t_max)), 1)) {
             return true;
         }
         return gates_pass(sc.gates, sc.gate_of, (uint32_t)best.prim, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max);
@@ -666,7 +666,7 @@ struct RayWalk {
             if (ODDITIES) weird = weird || t != t;
             // smallest t wins; equal t: larger shape index wins (bvh.rs:70-74)
             if (best.prim < 0 || t < best.t || (t == best.t && (int32_t)index > best.prim)) {
-                if (!careful || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max)) {
+                if (__builtin_expect(!careful, 1) || gates_pass(sc.gates, sc.gate_of, index, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max)) {
                     best = HitRec{t, (int32_t)index, (int32_t)((uint32_t)side | class_and_kind << CLASS_SHIFT)};
                     t_hi = fminf(t_hi, f32_not_below(t));
                 }

@@ -873,7 +873,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
                 have = false;
                 walk.reset();
             }
-            if (next >= chunk_end) {
+            if (__builtin_expect(next >= chunk_end, 0)) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(work, chunk);
                 base = __builtin_amdgcn_readfirstlane(base);
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(paths_block(TEXTURES)) __attribute__((amdgpu_waves_
             PS_START();
             shade_clock.start();
             __builtin_amdgcn_s_setprio(MIRT_PRIO_SHADE);
-            if (have && walk.finished() && !walk.confirm(sc, lds, rp.t_min, rp.t_max)) walk.begin_careful(sc, rp.t_min, rp.t_max);
+            if (have && walk.finished() && __builtin_expect(!walk.confirm(sc, lds, rp.t_min, rp.t_max), 0)) walk.begin_careful(sc, rp.t_min, rp.t_max);
             shade_clock.mark(0);
             // the samples of random_in_unit_sphere the hits of this trip will use: the whole wave works on them
             const bool shading = have && walk.finished();
