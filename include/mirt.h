@@ -277,7 +277,8 @@ int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out)
 void mirt_scene_destroy(mirt_scene* scene);
 
 /* Frees the per-pass buffers a render call left with the scene for the next one (by default up to
- * 13 GB, see mirt_render_opts.paths_per_pass); the next render call allocates them again.  For
+ * 13 GB, see mirt_render_opts.paths_per_pass) and mirt_render's accumulation image (27 bytes per
+ * pixel of the frame); the next render call allocates them again.  For
  * processes that hold several scenes or need the device memory for something else between frames. */
 int mirt_scene_trim(mirt_scene* scene);
 

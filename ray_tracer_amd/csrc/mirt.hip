@@ -111,6 +111,10 @@ struct mirt_scene {
     mutable std::mutex ws_mutex;
     mutable void* ws_ptr = nullptr;
     mutable size_t ws_bytes = 0;
+    // ... and a second one, kept the same way: the f64 accumulation image and the resolved bytes of mirt_render
+    // (23 + 3 MB for a 1200x800 frame: allocating and freeing them costs a call some 0.15 ms)
+    mutable void* frame_ptr = nullptr;
+    mutable size_t frame_bytes = 0;
 };
 
 namespace {
@@ -118,15 +122,19 @@ struct Workspace {
     const mirt_scene* scene = nullptr;
     void* ptr = nullptr;
     size_t bytes = 0;
-    hipError_t take(const mirt_scene* sc, size_t want) {
+    bool frame = false;  // the scene's second block (mirt_scene::frame_ptr) instead of its first
+    hipError_t take(const mirt_scene* sc, size_t want, bool frame_block = false) {
         scene = sc;
+        frame = frame_block;
         {
             std::lock_guard<std::mutex> lock(sc->ws_mutex);
-            if (sc->ws_ptr && sc->ws_bytes >= want) {
-                ptr = sc->ws_ptr;
-                bytes = sc->ws_bytes;
-                sc->ws_ptr = nullptr;
-                sc->ws_bytes = 0;
+            void*& kept = frame ? sc->frame_ptr : sc->ws_ptr;
+            size_t& kept_bytes = frame ? sc->frame_bytes : sc->ws_bytes;
+            if (kept && kept_bytes >= want) {
+                ptr = kept;
+                bytes = kept_bytes;
+                kept = nullptr;
+                kept_bytes = 0;
                 return hipSuccess;
             }
         }
@@ -140,10 +148,12 @@ struct Workspace {
         void* drop = ptr;
         {
             std::lock_guard<std::mutex> lock(scene->ws_mutex);
-            if (bytes > scene->ws_bytes) {
-                drop = scene->ws_ptr;
-                scene->ws_ptr = ptr;
-                scene->ws_bytes = bytes;
+            void*& kept = frame ? scene->frame_ptr : scene->ws_ptr;
+            size_t& kept_bytes = frame ? scene->frame_bytes : scene->ws_bytes;
+            if (bytes > kept_bytes) {
+                drop = kept;
+                kept = ptr;
+                kept_bytes = bytes;
             }
         }
         if (drop) (void)hipFree(drop);
@@ -493,24 +503,29 @@ void mirt_scene_destroy(mirt_scene* scene) {
     if (prev != scene->device) (void)hipSetDevice(scene->device);
     for (void* p : scene->allocations) (void)hipFree(p);
     if (scene->ws_ptr) (void)hipFree(scene->ws_ptr);
+    if (scene->frame_ptr) (void)hipFree(scene->frame_ptr);
     if (prev >= 0 && prev != scene->device) (void)hipSetDevice(prev);
     delete scene;
 }
 
 int mirt_scene_trim(mirt_scene* scene) {
     if (!scene) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene is null");
-    void* drop = nullptr;
+    void *drop = nullptr, *drop_frame = nullptr;
     {
         std::lock_guard<std::mutex> lock(scene->ws_mutex);
         drop = scene->ws_ptr;
         scene->ws_ptr = nullptr;
         scene->ws_bytes = 0;
+        drop_frame = scene->frame_ptr;
+        scene->frame_ptr = nullptr;
+        scene->frame_bytes = 0;
     }
-    if (!drop) return MIRT_OK;
+    if (!drop && !drop_frame) return MIRT_OK;
     DeviceGuard guard;
     int rc = guard.enter(scene->device);
     if (rc != MIRT_OK) return rc;
-    HIP_TRY(hipFree(drop));
+    if (drop) HIP_TRY(hipFree(drop));
+    if (drop_frame) HIP_TRY(hipFree(drop_frame));
     return MIRT_OK;
 }
 
@@ -1316,9 +1331,10 @@ int mirt_render_accumulate_static(const mirt_scene* scene, const mirt_camera* ca
     return no_throw([&] { return render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats, true); });
 }
 
+// d_bytes: device memory for the bytes of the selected pixels (3 per pixel of the range), or null: allocated here
 static int resolve_tiles_body(const double* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint32_t pixel_begin,
                               uint32_t pixel_end, uint32_t tile_size, uint32_t tile_count, uint32_t tile_index, int device,
-                              uint8_t* out_rgb) {
+                              uint8_t* out_rgb, uint8_t* d_bytes = nullptr) {
     if (!d_accum || !out_rgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "null argument");
     if (width == 0 || height == 0 || spp == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "empty image or spp = 0");
     if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(MIRT_ERR_UNSUPPORTED, "more than 2^31 pixels");
@@ -1338,8 +1354,8 @@ static int resolve_tiles_body(const double* d_accum, uint32_t width, uint32_t he
     const uint32_t n = px.n_pixels;
     if (n == 0) return MIRT_OK;
     DeviceArena arena;
-    uint8_t* d_out = nullptr;
-    HIP_TRY(arena.alloc(&d_out, (size_t)n * 3));
+    uint8_t* d_out = d_bytes;
+    if (!d_out) HIP_TRY(arena.alloc(&d_out, (size_t)n * 3));
     const int grid = (int)std::min<size_t>(((size_t)n + BLOCK - 1) / BLOCK, 4096);
     hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, 0, d_accum, px, spp, d_out);
     HIP_TRY(hipGetLastError());
@@ -1378,10 +1394,13 @@ static int mirt_render_body(const mirt_scene* scene, const mirt_camera* camera, 
     DeviceGuard guard;
     int rc = guard.enter(scene->device);
     if (rc != MIRT_OK) return rc;
-    DeviceArena arena;
-    double* d_accum = nullptr;
+    // the f64 accumulation image and, behind it, the resolved bytes: one block that stays with the scene
     const size_t n_values = (size_t)width * height * 3;
-    HIP_TRY(arena.alloc(&d_accum, n_values));
+    const size_t accum_bytes = (n_values * sizeof(double) + 255) & ~(size_t)255;
+    Workspace frame;
+    HIP_TRY(frame.take(scene, accum_bytes + n_values, true));
+    double* d_accum = static_cast<double*>(frame.ptr);
+    uint8_t* d_bytes = static_cast<uint8_t*>(frame.ptr) + accum_bytes;
     HIP_TRY(hipMemsetAsync(d_accum, 0, n_values * sizeof(double), 0));
     rc = render_accumulate_impl(scene, camera, background, width, height, spp, max_depth, seed, opts, d_accum, stats);
     if (rc != MIRT_OK) return rc;
@@ -1393,8 +1412,8 @@ static int mirt_render_body(const mirt_scene* scene, const mirt_camera* camera, 
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, 0));
     }
-    rc = mirt_resolve_tiles(d_accum, width, height, spp, pb, pe, opts ? opts->tile_size : 0, opts ? opts->tile_count : 1,
-                            opts ? opts->tile_index : 0, scene->device, out_rgb);
+    rc = resolve_tiles_body(d_accum, width, height, spp, pb, pe, opts ? opts->tile_size : 0, opts ? opts->tile_count : 1,
+                            opts ? opts->tile_index : 0, scene->device, out_rgb, d_bytes);
     if (prof) {
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
