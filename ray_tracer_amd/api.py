@@ -131,7 +131,7 @@ class Scene:
         return self._handle
 
     def trim(self):
-        """Frees the per-pass buffers render calls keep with the scene (mirt_scene_trim)."""
+        """Frees the per-pass buffers and the accumulation image render calls keep with the scene (mirt_scene_trim)."""
         _check(self._lib.mirt_scene_trim(self._handle))
 
     def close(self):

@@ -139,3 +139,30 @@ def test_a_pixel_range_of_one_pixel_and_the_last_pixel(worlds, oracle):
             assert np.all(rest == 77), idx
     finally:
         scene.close()
+
+
+def test_a_scene_keeps_its_buffers_between_calls_and_trim_frees_them(worlds):
+    """mirt_render leaves its per-pass records, the f64 accumulation image and the byte buffer with the scene: the next
+    call of the same size allocates nothing, mirt_scene_trim gives the memory back, and the call after that renders
+    the same bytes again."""
+    import torch
+
+    cfg = configs.C1
+    w, h, spp = 1024, 576, 2  # 14 MB of f64 image, 28 MB of records: large enough to show in the device's free memory
+    scene = api.Scene(worlds("C1"))
+    try:
+        cam = cfg.camera(w, h)
+        first = api.render_world(cfg.background, scene, cam, w, h, spp)
+        free_kept, _ = torch.cuda.mem_get_info()
+        again = api.render_world(cfg.background, scene, cam, w, h, spp)
+        free_after, _ = torch.cuda.mem_get_info()
+        assert np.array_equal(first, again) and free_after == free_kept
+        scene.trim()
+        free_trimmed, _ = torch.cuda.mem_get_info()
+        assert free_trimmed >= free_kept + (w * h * (3 * 8 + 3) + w * h * spp * 24) // 2
+        assert np.array_equal(api.render_world(cfg.background, scene, cam, w, h, spp), first)
+        # a smaller frame after a larger one works in the larger one's buffers
+        small = api.render_world(cfg.background, scene, cfg.camera(64, 36), 64, 36, spp)
+        assert small.shape == (36, 64, 3)
+    finally:
+        scene.close()
